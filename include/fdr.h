@@ -1,0 +1,124 @@
+/*
+ * fdr.h -- C ABI of libfdr.so: the MI355X (gfx950) frequency-domain restoration path.
+ *
+ * This is the drop-in boundary for the reference's GPU operator surface.  Every entry point
+ * names the reference interface it stands in for (paths relative to the reference repo).
+ * Plain pointers and sizes only; no C++ or torch types; every function returns an int status
+ * (FDR_OK or a negative FDR_ERR_*), never throws, and leaves a message for fdr_last_error().
+ * `stream` arguments are a hipStream_t passed as void* (NULL = the null stream).
+ *
+ * The C++ shim with the reference's own names (fft_gpu::wienerDeblur_RGB_optimized etc.,
+ * fft/fft.hpp:31-45) lives in include/fft/fft.hpp and calls only these functions.
+ */
+#ifndef FDR_H
+#define FDR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDR_VERSION 100 /* 0.1.0 */
+
+/* status codes (reference: CHECK_CUDA prints and exit(1)s, fft/fft_gpu.cu:59-66; the C++ shim
+ * reproduces that on any non-zero status) */
+#define FDR_OK 0
+#define FDR_ERR_ARG (-1)      /* null pointer, non-positive size, PSF larger than the plan ... */
+#define FDR_ERR_NOT_POW2 (-2) /* plan dimensions must be powers of two (callers pad first,
+                                 as fft/fft_gpu.cu:287-288 and serial.cpp:36 do)            */
+#define FDR_ERR_HIP (-3)      /* a HIP runtime call failed; message holds hipGetErrorString  */
+#define FDR_ERR_STATE (-4)    /* e.g. fdr_wiener_* before fdr_set_psf*                        */
+#define FDR_ERR_ALLOC (-5)
+
+/* arithmetic modes of a plan */
+#define FDR_MODE_PARITY 0 /* reference operation order (rows, cols, Wiener, rows, cols), per-stage
+                             twiddles replayed from the float recurrence of fft/fft_serial.cpp:54-63,
+                             no FMA contraction: bit-identical to the serial path's FFT arithmetic */
+#define FDR_MODE_FAST 1   /* fused column pass (FFT . Wiener . IFFT), double-generated twiddles (as
+                             fft/fft_gpu.cu:206-212), FMA butterflies; within 1e-4 of the serial path */
+
+/* plan flags */
+#define FDR_FLAG_SIMPLE_PATH 1u /* reference-shaped kernels: row FFT, transpose, row FFT, transpose
+                                   (fft/fft_gpu.cu:214-240); slow, used as an on-device cross-check */
+
+/* normalisation area selector for fdr_wiener_* */
+#define FDR_NORM_PADDED 1  /* serial semantics: min/max over the padded M x N area, then crop
+                              (serial.cpp:36-38 + fft/fft_serial.cpp:243-246)                 */
+#define FDR_NORM_CROPPED 0 /* reference GPU semantics: min/max over the cropped rows x cols
+                              area only (fft/fft_gpu.cu:379-381)                              */
+
+typedef struct fdr_plan fdr_plan;
+
+int fdr_version(void);
+/* thread-local message of the last failing call on this thread */
+const char* fdr_last_error(void);
+int fdr_device_count(int* count);
+
+/* -- utils.hpp:27-37,50-52 ------------------------------------------------------------- */
+int fdr_next_pow2(int n);
+int fdr_is_pow2(int n);
+
+/* -- plan: owns twiddle tables, the M x N complex workspace, the filter spectrum and the
+ *    min/max scratch for one device.  Replaces the per-call cudaMalloc/cudaFree block of
+ *    fft/fft_gpu.cu:304-322,389-393.  One host thread at a time per plan.               */
+int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan** out);
+int fdr_plan_destroy(fdr_plan* plan);
+int fdr_plan_dims(const fdr_plan* plan, int* M, int* N, int* mode);
+
+/* -- PSF generation: utils.hpp:15-24 motionBlurKernel(size, angle) ------------------- */
+/* host result, size*size floats (computed on the device by the psf kernel, copied back) */
+int fdr_psf_motion(int size, double angle_deg, float* out_host);
+/* device result into d_out (size*size floats), asynchronous on stream */
+int fdr_psf_motion_dev(int device, int size, double angle_deg, float* d_out, void* stream);
+
+/* -- PSF spectrum: pad top-left + forward 2-D FFT (fft/fft_serial.cpp:166-171,182;
+ *    fft/fft_gpu.cu:340,356), kept in the plan together with K.                        */
+int fdr_set_psf(fdr_plan* plan, const float* psf_host, int prows, int pcols, int pstride, float K);
+int fdr_set_psf_dev(fdr_plan* plan, const float* d_psf, int prows, int pcols, int pstride, float K, void* stream);
+/* motionBlurKernel on the device straight into the plan (no host round trip) */
+int fdr_set_psf_motion(fdr_plan* plan, int size, double angle_deg, float K, void* stream);
+
+/* -- the operator: fft_serial::wienerDeblur_myfft (fft/fft_serial.cpp:141-261) wrapped as
+ *    serial.cpp:34-39 does (pad -> restore -> crop), one channel.  img rows x cols with row
+ *    stride `stride` (elements); out rows x cols with row stride `out_stride`, values in [0,1].
+ *    rows <= M, cols <= N.  Host-pointer form copies in and out synchronously; the _dev form
+ *    is asynchronous on `stream` and touches only device memory.                         */
+int fdr_wiener_f32(fdr_plan* plan, const float* img_host, int rows, int cols, int stride,
+                   float* out_host, int out_stride, int norm_area);
+int fdr_wiener_f32_dev(fdr_plan* plan, const float* d_img, int rows, int cols, int stride,
+                       float* d_out, int out_stride, int norm_area, void* stream);
+/* `count` independent images, image i at d_imgs + i*img_pitch / d_out + i*out_pitch (elements);
+ * the batched mode of BASELINE config 5 (one plan, one PSF spectrum, many images).      */
+int fdr_wiener_batch_f32_dev(fdr_plan* plan, const float* d_imgs, size_t img_pitch, int count,
+                             int rows, int cols, int stride,
+                             float* d_out, size_t out_pitch, int out_stride, int norm_area, void* stream);
+
+/* -- fft_gpu::my_dft2D(Mat&, bool) (fft/fft.hpp:40; empty body at fft/fft_gpu.cu:515):
+ *    in-place unscaled 2-D transform of M x N interleaved complex.                       */
+int fdr_fft2d_c2c(fdr_plan* plan, float* data_host, int inverse);
+int fdr_fft2d_c2c_dev(fdr_plan* plan, float* d_data, int inverse, void* stream);
+
+/* -- fft_gpu::fft_radix2_kernel / transform_row_kernel / dft_naive_kernel (fft/fft.hpp:35-39;
+ *    declared, never defined in the reference): 1-D unscaled transform of n interleaved
+ *    complex values given by host pointer.  fft1d: power-of-two n (radix-2) else naive DFT,
+ *    as fft_serial::transform_row_inplace dispatches (fft/fft_serial.cpp:100-101).        */
+int fdr_fft1d_c2c(float* data_host, int n, int inverse, int mode);
+int fdr_dft_naive_c2c(float* data_host, int n, int inverse);
+
+/* -- synthetic input: pixel i = top 24 bits of splitmix64(seed+first+i) / 2^24 */
+int fdr_synth_image_dev(int device, uint64_t seed, uint64_t first_index, size_t count, float* d_out, void* stream);
+
+/* -- per-pass device timing (the reference's Profiler buckets, fft/fft_gpu.cu:17-57).
+ *    With profiling on, every fdr_wiener_*_dev call records a hipEvent pair around each
+ *    kernel on the call's stream; fdr_plan_pass_times synchronises and returns the mean
+ *    duration in ms of each pass since the last reset, names[i] a static string.         */
+#define FDR_MAX_PASSES 8
+int fdr_plan_profile(fdr_plan* plan, int enable);
+int fdr_plan_pass_times(fdr_plan* plan, int* n_passes, float* mean_ms, const char** names, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDR_H */

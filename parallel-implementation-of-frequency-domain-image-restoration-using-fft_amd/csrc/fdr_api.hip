@@ -1,0 +1,539 @@
+// fdr_api.hip -- host side of libfdr.so: plans, twiddle tables, pass sequencing, the C ABI of
+// include/fdr.h.  No torch, no OpenCV; only the HIP runtime.  There is deliberately NO CPU
+// fallback anywhere in this file: every entry point either launches HIP kernels or fails.
+#include "../../include/fdr.h"
+#include "fdr_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace fdr;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define FDR_HIP(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            char buf_[512];                                                                        \
+            snprintf(buf_, sizeof buf_, "%s:%d: %s: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return fail(FDR_ERR_HIP, buf_);                                                        \
+        }                                                                                          \
+    } while (0)
+
+int ilog2(int n) {
+    int l = 0;
+    while ((1 << l) < n) ++l;
+    return l;
+}
+
+// Per-stage twiddle table for transforms of length n: stage len = 2,4,..,n at offset len/2-1.
+// parity: replay of fft/fft_serial.cpp:54-63 -- ang evaluated in double and rounded to float,
+//         wlen = (cosf(ang), sinf(ang)), w advanced by the float recurrence w *= wlen.
+// fast  : exp(-+2 pi i k / len) evaluated in double (as fft/fft_gpu.cu:206-212), rounded once.
+void build_twiddles(int n, int mode, bool inverse, std::vector<float2>& out) {
+    out.assign(n > 1 ? (size_t)n - 1 : 1, make_float2(1.f, 0.f));
+    const double PI = 3.1415926535897932384626433832795;  // CV_PI
+    for (int len = 2; len <= n; len <<= 1) {
+        float2* t = out.data() + (len / 2 - 1);
+        if (mode == FDR_MODE_PARITY) {
+            const float ang = (float)((double)2.0f * PI / (double)len * (double)(inverse ? 1.0f : -1.0f));
+            const float wlr = cosf(ang), wli = sinf(ang);
+            float wr = 1.0f, wi = 0.0f;
+            for (int k = 0; k < len / 2; ++k) {
+                t[k] = make_float2(wr, wi);
+                const float ac = wr * wlr, bd = wi * wli, ad = wr * wli, bc = wi * wlr;
+                wr = ac - bd;
+                wi = ad + bc;
+            }
+        } else {
+            for (int k = 0; k < len / 2; ++k) {
+                const double a = (inverse ? 2.0 : -2.0) * PI * (double)k / (double)len;
+                t[k] = make_float2((float)cos(a), (float)sin(a));
+            }
+        }
+    }
+}
+
+struct PassTimer {
+    static constexpr int kMaxRecords = 8192;
+    struct Rec { hipEvent_t a, b; int pass; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    bool enabled = false;
+    const char* names[FDR_MAX_PASSES] = {nullptr};
+    int n_names = 0;
+
+    int pass_id(const char* name) {
+        for (int i = 0; i < n_names; ++i)
+            if (names[i] == name) return i;
+        if (n_names < FDR_MAX_PASSES) { names[n_names] = name; return n_names++; }
+        return FDR_MAX_PASSES - 1;
+    }
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void reset() {
+        for (auto& r : recs) { pool.push_back(r.a); pool.push_back(r.b); }
+        recs.clear();
+    }
+    void destroy() {
+        reset();
+        for (auto e : pool) (void)hipEventDestroy(e);
+        pool.clear();
+    }
+};
+
+}  // namespace
+
+struct fdr_plan {
+    int device = 0, M = 0, N = 0, logM = 0, logN = 0, mode = 0;
+    unsigned flags = 0;
+    bool simple = false;
+    float2 *tw_row_f = nullptr, *tw_row_i = nullptr, *tw_col_f = nullptr, *tw_col_i = nullptr;
+    float2* work = nullptr;   // M x N complex working spectrum
+    float2* work2 = nullptr;  // simple path: N x M transpose buffer
+    float2* filt = nullptr;   // H (parity) or W (fast)
+    float* raw = nullptr;     // M x N real plane before normalisation
+    float* psf_dev = nullptr; // staging for host-pointer / generated PSFs
+    size_t psf_cap = 0;
+    unsigned* mm = nullptr;
+    float K = 0.f;
+    bool have_psf = false;
+    PassTimer timer;
+};
+
+namespace {
+
+struct ScopedPass {
+    fdr_plan* p; hipStream_t s; PassTimer::Rec rec; bool on;
+    ScopedPass(fdr_plan* plan, hipStream_t st, const char* name) : p(plan), s(st), on(false) {
+        if (p->timer.enabled && (int)p->timer.recs.size() < PassTimer::kMaxRecords) {
+            rec.a = p->timer.get(); rec.b = p->timer.get(); rec.pass = p->timer.pass_id(name);
+            on = rec.a && rec.b;
+            if (on) (void)hipEventRecord(rec.a, s);
+        }
+    }
+    ~ScopedPass() {
+        if (on) { (void)hipEventRecord(rec.b, s); p->timer.recs.push_back(rec); }
+    }
+};
+
+// names are static strings compared by pointer in PassTimer::pass_id
+const char* const kPassRowsFwd = "A rows: pad+FFT (real->complex)";
+const char* const kPassColsWiener = "B cols: FFT+Wiener";
+const char* const kPassRowsInv = "C rows: IFFT (complex)";
+const char* const kPassColsInvReal = "D cols: IFFT+real+minmax";
+const char* const kPassColsFused = "B' cols: FFT*W*IFFT";
+const char* const kPassRowsInvReal = "C' rows: IFFT+real+minmax";
+const char* const kPassNormalize = "E normalize+crop";
+const char* const kPassSimple = "simple path (reference-shaped)";
+
+int upload(float2** dst, const std::vector<float2>& v) {
+    FDR_HIP(hipMalloc((void**)dst, v.size() * sizeof(float2)));
+    FDR_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(float2), hipMemcpyHostToDevice));
+    return FDR_OK;
+}
+
+// unscaled 2-D transform in place on d (M x N), rows then columns as fft/fft_serial.cpp:113-139
+int dft2d_dev(fdr_plan* p, float2* d, bool inverse, hipStream_t s) {
+    const float2* twr = inverse ? p->tw_row_i : p->tw_row_f;
+    const float2* twc = inverse ? p->tw_col_i : p->tw_col_f;
+    if (p->simple) {
+        FDR_HIP(launch_simple_rows(d, p->M, p->N, p->logN, twr, p->mode, s));
+        FDR_HIP(launch_transpose(d, p->work2, p->M, p->N, s));
+        FDR_HIP(launch_simple_rows(p->work2, p->N, p->M, p->logM, twc, p->mode, s));
+        FDR_HIP(launch_transpose(p->work2, d, p->N, p->M, s));
+        return FDR_OK;
+    }
+    RowArgs ra{};
+    ra.src_c = d; ra.dst_c = d; ra.M = p->M;
+    FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, ra, twr, s));
+    ColArgs ca{};
+    ca.data = d; ca.N = p->N;
+    FDR_HIP(launch_cols(p->logM, p->mode, inverse ? COL_INV : COL_FWD, ca, p->tw_col_f, p->tw_col_i, s));
+    return FDR_OK;
+}
+
+int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int pstride, float K, hipStream_t s) {
+    if (prows <= 0 || pcols <= 0 || pstride < pcols) return fail(FDR_ERR_ARG, "fdr_set_psf: bad PSF shape");
+    if (prows > p->M || pcols > p->N)
+        return fail(FDR_ERR_ARG, "fdr_set_psf: PSF larger than the padded image (copyMakeBorder would throw, fft_serial.cpp:168)");
+    // pad top-left + forward 2-D FFT (fft/fft_serial.cpp:166-171,182)
+    if (p->simple) {
+        FDR_HIP(launch_pad_real_to_complex(d_psf, prows, pcols, pstride, p->filt, p->M, p->N, nullptr, s));
+        int rc = dft2d_dev(p, p->filt, false, s);
+        if (rc != FDR_OK) return rc;
+    } else {
+        RowArgs ra{};
+        ra.src_real = d_psf; ra.src_rows = prows; ra.src_cols = pcols; ra.src_stride = pstride;
+        ra.dst_c = p->filt; ra.M = p->M;
+        FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_REAL, ROW_OUT_COMPLEX, ra, p->tw_row_f, s));
+        ColArgs ca{};
+        ca.data = p->filt; ca.N = p->N;
+        FDR_HIP(launch_cols(p->logM, p->mode, COL_FWD, ca, p->tw_col_f, p->tw_col_i, s));
+    }
+    if (p->mode == FDR_MODE_FAST)
+        FDR_HIP(launch_make_filter_fast(p->filt, p->filt, (size_t)p->M * p->N, K, s));
+    p->K = K;
+    p->have_psf = true;
+    return FDR_OK;
+}
+
+int wiener_dev_impl(fdr_plan* p, const float* d_img, int rows, int cols, int stride, float* d_out, int out_stride,
+                    int norm_area, hipStream_t s) {
+    if (!p->have_psf) return fail(FDR_ERR_STATE, "fdr_wiener: no PSF set on this plan (call fdr_set_psf* first)");
+    if (!d_img || !d_out) return fail(FDR_ERR_ARG, "fdr_wiener: null image pointer");
+    if (rows <= 0 || cols <= 0 || rows > p->M || cols > p->N || stride < cols || out_stride < cols)
+        return fail(FDR_ERR_ARG, "fdr_wiener: image shape does not fit the plan");
+    const int mm_rows = norm_area == FDR_NORM_PADDED ? p->M : rows;
+    const int mm_cols = norm_area == FDR_NORM_PADDED ? p->N : cols;
+    const size_t P = (size_t)p->M * p->N;
+
+    if (p->simple) {
+        ScopedPass t(p, s, kPassSimple);
+        FDR_HIP(launch_pad_real_to_complex(d_img, rows, cols, stride, p->work, p->M, p->N, p->mm, s));
+        int rc = dft2d_dev(p, p->work, false, s);
+        if (rc != FDR_OK) return rc;
+        FDR_HIP(launch_wiener_pointwise(p->work, p->filt, P, p->K, p->mode, s));
+        rc = dft2d_dev(p, p->work, true, s);
+        if (rc != FDR_OK) return rc;
+        FDR_HIP(launch_real_minmax(p->work, p->raw, p->M, p->N, mm_rows, mm_cols, p->mm, s));
+    } else if (p->mode == FDR_MODE_PARITY) {
+        {   // A: rows, real -> complex (fft/fft_serial.cpp:157-165,176 first half)
+            ScopedPass t(p, s, kPassRowsFwd);
+            RowArgs a{};
+            a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
+            a.dst_c = p->work; a.M = p->M; a.mm_init = p->mm;
+            FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
+        }
+        {   // B: columns forward + Wiener quotient (:176 second half, :186-224)
+            ScopedPass t(p, s, kPassColsWiener);
+            ColArgs c{};
+            c.data = p->work; c.filt = p->filt; c.K = p->K; c.N = p->N;
+            FDR_HIP(launch_cols(p->logM, p->mode, COL_FWD_WIENER, c, p->tw_col_f, p->tw_col_i, s));
+        }
+        {   // C: rows inverse (:229 first half)
+            ScopedPass t(p, s, kPassRowsInv);
+            RowArgs a{};
+            a.src_c = p->work; a.dst_c = p->work; a.M = p->M;
+            FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, a, p->tw_row_i, s));
+        }
+        {   // D: columns inverse, real plane, min/max (:229 second half, :236-240, minMaxIdx of :246)
+            ScopedPass t(p, s, kPassColsInvReal);
+            ColArgs c{};
+            c.data = p->work; c.dst_real = p->raw; c.mm = p->mm; c.mm_rows = mm_rows; c.mm_cols = mm_cols; c.N = p->N;
+            FDR_HIP(launch_cols(p->logM, p->mode, COL_INV_REAL, c, p->tw_col_f, p->tw_col_i, s));
+        }
+    } else {
+        {   // A
+            ScopedPass t(p, s, kPassRowsFwd);
+            RowArgs a{};
+            a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
+            a.dst_c = p->work; a.M = p->M; a.mm_init = p->mm;
+            FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
+        }
+        {   // B': columns forward, multiply by W, columns inverse -- one HBM round trip
+            ScopedPass t(p, s, kPassColsFused);
+            ColArgs c{};
+            c.data = p->work; c.filt = p->filt; c.K = p->K; c.N = p->N;
+            FDR_HIP(launch_cols(p->logM, p->mode, COL_FUSED, c, p->tw_col_f, p->tw_col_i, s));
+        }
+        {   // C': rows inverse, real plane, min/max
+            ScopedPass t(p, s, kPassRowsInvReal);
+            RowArgs a{};
+            a.src_c = p->work; a.dst_real = p->raw; a.mm = p->mm; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
+            FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, a, p->tw_row_i, s));
+        }
+    }
+    {   // E: normalise to [0,1] and crop (fft/fft_serial.cpp:246, serial.cpp:38)
+        ScopedPass t(p, s, kPassNormalize);
+        FDR_HIP(launch_normalize(p->raw, p->N, p->mm, d_out, rows, cols, out_stride, p->mode, s));
+    }
+    return FDR_OK;
+}
+
+int ensure_psf_staging(fdr_plan* p, size_t elems) {
+    if (p->psf_cap >= elems) return FDR_OK;
+    if (p->psf_dev) { (void)hipFree(p->psf_dev); p->psf_dev = nullptr; p->psf_cap = 0; }
+    FDR_HIP(hipMalloc((void**)&p->psf_dev, elems * sizeof(float)));
+    p->psf_cap = elems;
+    return FDR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fdr_version(void) { return FDR_VERSION; }
+const char* fdr_last_error(void) { return g_last_error.c_str(); }
+
+int fdr_device_count(int* count) {
+    if (!count) return fail(FDR_ERR_ARG, "fdr_device_count: null");
+    FDR_HIP(hipGetDeviceCount(count));
+    return FDR_OK;
+}
+
+int fdr_next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }  // utils.hpp:27-37
+int fdr_is_pow2(int n) { return n > 0 && ((n & (n - 1)) == 0); }           // utils.hpp:50-52
+
+int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan** out) {
+    if (!out) return fail(FDR_ERR_ARG, "fdr_plan_create: null out");
+    *out = nullptr;
+    if (M <= 0 || N <= 0) return fail(FDR_ERR_ARG, "fdr_plan_create: non-positive dimension");
+    if (!fdr_is_pow2(M) || !fdr_is_pow2(N))
+        return fail(FDR_ERR_NOT_POW2, "fdr_plan_create: M and N must be powers of two (pad first, utils.hpp:40-47)");
+    if (M > 8192 || N > 8192) return fail(FDR_ERR_ARG, "fdr_plan_create: dimension above 8192 (one row must fit LDS)");
+    if (mode != FDR_MODE_PARITY && mode != FDR_MODE_FAST) return fail(FDR_ERR_ARG, "fdr_plan_create: unknown mode");
+    FDR_HIP(hipSetDevice(device));
+    fdr_plan* p = new (std::nothrow) fdr_plan();
+    if (!p) return fail(FDR_ERR_ALLOC, "fdr_plan_create: out of host memory");
+    p->device = device; p->M = M; p->N = N; p->logM = ilog2(M); p->logN = ilog2(N); p->mode = mode; p->flags = flags;
+    p->simple = (flags & FDR_FLAG_SIMPLE_PATH) != 0 || M < 8 || N < 8;
+    const size_t P = (size_t)M * N;
+    std::vector<float2> t;
+    int rc = FDR_OK;
+    build_twiddles(N, mode, false, t); if ((rc = upload(&p->tw_row_f, t)) != FDR_OK) goto bad;
+    build_twiddles(N, mode, true, t);  if ((rc = upload(&p->tw_row_i, t)) != FDR_OK) goto bad;
+    build_twiddles(M, mode, false, t); if ((rc = upload(&p->tw_col_f, t)) != FDR_OK) goto bad;
+    build_twiddles(M, mode, true, t);  if ((rc = upload(&p->tw_col_i, t)) != FDR_OK) goto bad;
+    if (hipMalloc((void**)&p->work, P * sizeof(float2)) != hipSuccess ||
+        hipMalloc((void**)&p->filt, P * sizeof(float2)) != hipSuccess ||
+        hipMalloc((void**)&p->raw, P * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&p->mm, 2 * sizeof(unsigned)) != hipSuccess ||
+        (p->simple && hipMalloc((void**)&p->work2, P * sizeof(float2)) != hipSuccess)) {
+        rc = fail(FDR_ERR_ALLOC, "fdr_plan_create: hipMalloc of the plan workspace failed");
+        goto bad;
+    }
+    *out = p;
+    return FDR_OK;
+bad:
+    fdr_plan_destroy(p);
+    return rc;
+}
+
+int fdr_plan_destroy(fdr_plan* p) {
+    if (!p) return FDR_OK;
+    (void)hipSetDevice(p->device);
+    p->timer.destroy();
+    (void)hipFree(p->tw_row_f); (void)hipFree(p->tw_row_i); (void)hipFree(p->tw_col_f); (void)hipFree(p->tw_col_i);
+    (void)hipFree(p->work); (void)hipFree(p->work2); (void)hipFree(p->filt); (void)hipFree(p->raw);
+    (void)hipFree(p->psf_dev); (void)hipFree(p->mm);
+    delete p;
+    return FDR_OK;
+}
+
+int fdr_plan_dims(const fdr_plan* p, int* M, int* N, int* mode) {
+    if (!p) return fail(FDR_ERR_ARG, "fdr_plan_dims: null plan");
+    if (M) *M = p->M;
+    if (N) *N = p->N;
+    if (mode) *mode = p->mode;
+    return FDR_OK;
+}
+
+int fdr_psf_motion_dev(int device, int size, double angle_deg, float* d_out, void* stream) {
+    if (size <= 0 || !d_out) return fail(FDR_ERR_ARG, "fdr_psf_motion_dev: bad argument");
+    FDR_HIP(hipSetDevice(device));
+    FDR_HIP(launch_psf_motion(size, angle_deg, d_out, (hipStream_t)stream));
+    return FDR_OK;
+}
+
+int fdr_psf_motion(int size, double angle_deg, float* out_host) {
+    if (size <= 0 || !out_host) return fail(FDR_ERR_ARG, "fdr_psf_motion: bad argument");
+    float* d = nullptr;
+    const size_t bytes = (size_t)size * size * sizeof(float);
+    FDR_HIP(hipMalloc((void**)&d, bytes));
+    hipError_t e = launch_psf_motion(size, angle_deg, d, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_host, d, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    FDR_HIP(e);
+    return FDR_OK;
+}
+
+int fdr_set_psf_dev(fdr_plan* p, const float* d_psf, int prows, int pcols, int pstride, float K, void* stream) {
+    if (!p || !d_psf) return fail(FDR_ERR_ARG, "fdr_set_psf_dev: null argument");
+    FDR_HIP(hipSetDevice(p->device));
+    return set_psf_dev_impl(p, d_psf, prows, pcols, pstride, K, (hipStream_t)stream);
+}
+
+int fdr_set_psf(fdr_plan* p, const float* psf_host, int prows, int pcols, int pstride, float K) {
+    if (!p || !psf_host) return fail(FDR_ERR_ARG, "fdr_set_psf: null argument");
+    if (prows <= 0 || pcols <= 0 || pstride < pcols) return fail(FDR_ERR_ARG, "fdr_set_psf: bad PSF shape");
+    FDR_HIP(hipSetDevice(p->device));
+    int rc = ensure_psf_staging(p, (size_t)prows * pcols);
+    if (rc != FDR_OK) return rc;
+    FDR_HIP(hipMemcpy2D(p->psf_dev, (size_t)pcols * sizeof(float), psf_host, (size_t)pstride * sizeof(float),
+                        (size_t)pcols * sizeof(float), prows, hipMemcpyHostToDevice));
+    rc = set_psf_dev_impl(p, p->psf_dev, prows, pcols, pcols, K, nullptr);
+    if (rc != FDR_OK) return rc;
+    FDR_HIP(hipStreamSynchronize(nullptr));
+    return FDR_OK;
+}
+
+int fdr_set_psf_motion(fdr_plan* p, int size, double angle_deg, float K, void* stream) {
+    if (!p || size <= 0) return fail(FDR_ERR_ARG, "fdr_set_psf_motion: bad argument");
+    FDR_HIP(hipSetDevice(p->device));
+    int rc = ensure_psf_staging(p, (size_t)size * size);
+    if (rc != FDR_OK) return rc;
+    FDR_HIP(launch_psf_motion(size, angle_deg, p->psf_dev, (hipStream_t)stream));
+    return set_psf_dev_impl(p, p->psf_dev, size, size, size, K, (hipStream_t)stream);
+}
+
+int fdr_wiener_f32_dev(fdr_plan* p, const float* d_img, int rows, int cols, int stride, float* d_out, int out_stride,
+                       int norm_area, void* stream) {
+    if (!p) return fail(FDR_ERR_ARG, "fdr_wiener_f32_dev: null plan");
+    FDR_HIP(hipSetDevice(p->device));
+    return wiener_dev_impl(p, d_img, rows, cols, stride, d_out, out_stride, norm_area, (hipStream_t)stream);
+}
+
+int fdr_wiener_batch_f32_dev(fdr_plan* p, const float* d_imgs, size_t img_pitch, int count, int rows, int cols, int stride,
+                             float* d_out, size_t out_pitch, int out_stride, int norm_area, void* stream) {
+    if (!p) return fail(FDR_ERR_ARG, "fdr_wiener_batch_f32_dev: null plan");
+    if (count < 0) return fail(FDR_ERR_ARG, "fdr_wiener_batch_f32_dev: negative count");
+    FDR_HIP(hipSetDevice(p->device));
+    for (int i = 0; i < count; ++i) {
+        int rc = wiener_dev_impl(p, d_imgs + (size_t)i * img_pitch, rows, cols, stride, d_out + (size_t)i * out_pitch,
+                                 out_stride, norm_area, (hipStream_t)stream);
+        if (rc != FDR_OK) return rc;
+    }
+    return FDR_OK;
+}
+
+int fdr_wiener_f32(fdr_plan* p, const float* img_host, int rows, int cols, int stride, float* out_host, int out_stride,
+                   int norm_area) {
+    if (!p || !img_host || !out_host) return fail(FDR_ERR_ARG, "fdr_wiener_f32: null argument");
+    if (rows <= 0 || cols <= 0 || rows > p->M || cols > p->N || stride < cols || out_stride < cols)
+        return fail(FDR_ERR_ARG, "fdr_wiener_f32: image shape does not fit the plan");
+    FDR_HIP(hipSetDevice(p->device));
+    float *d_in = nullptr, *d_out = nullptr;
+    const size_t bytes = (size_t)rows * cols * sizeof(float);
+    FDR_HIP(hipMalloc((void**)&d_in, bytes));
+    if (hipMalloc((void**)&d_out, bytes) != hipSuccess) { (void)hipFree(d_in); return fail(FDR_ERR_ALLOC, "fdr_wiener_f32: hipMalloc"); }
+    hipError_t e = hipMemcpy2D(d_in, (size_t)cols * sizeof(float), img_host, (size_t)stride * sizeof(float),
+                               (size_t)cols * sizeof(float), rows, hipMemcpyHostToDevice);
+    int rc = FDR_OK;
+    if (e == hipSuccess) rc = wiener_dev_impl(p, d_in, rows, cols, cols, d_out, cols, norm_area, nullptr);
+    if (e == hipSuccess && rc == FDR_OK)
+        e = hipMemcpy2D(out_host, (size_t)out_stride * sizeof(float), d_out, (size_t)cols * sizeof(float),
+                        (size_t)cols * sizeof(float), rows, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    if (rc != FDR_OK) return rc;
+    FDR_HIP(e);
+    return FDR_OK;
+}
+
+int fdr_fft2d_c2c_dev(fdr_plan* p, float* d_data, int inverse, void* stream) {
+    if (!p || !d_data) return fail(FDR_ERR_ARG, "fdr_fft2d_c2c_dev: null argument");
+    FDR_HIP(hipSetDevice(p->device));
+    return dft2d_dev(p, reinterpret_cast<float2*>(d_data), inverse != 0, (hipStream_t)stream);
+}
+
+int fdr_fft2d_c2c(fdr_plan* p, float* data_host, int inverse) {
+    if (!p || !data_host) return fail(FDR_ERR_ARG, "fdr_fft2d_c2c: null argument");
+    FDR_HIP(hipSetDevice(p->device));
+    const size_t bytes = (size_t)p->M * p->N * sizeof(float2);
+    // p->work is free between operator calls; use it as the staging buffer
+    FDR_HIP(hipMemcpy(p->work, data_host, bytes, hipMemcpyHostToDevice));
+    int rc = dft2d_dev(p, p->work, inverse != 0, nullptr);
+    if (rc != FDR_OK) return rc;
+    FDR_HIP(hipMemcpy(data_host, p->work, bytes, hipMemcpyDeviceToHost));
+    return FDR_OK;
+}
+
+int fdr_dft_naive_c2c(float* data_host, int n, int inverse) {
+    if (!data_host || n < 0) return fail(FDR_ERR_ARG, "fdr_dft_naive_c2c: bad argument");
+    if (n <= 1) return FDR_OK;  // fft/fft_serial.cpp:74
+    float2 *a = nullptr, *b = nullptr;
+    const size_t bytes = (size_t)n * sizeof(float2);
+    FDR_HIP(hipMalloc((void**)&a, bytes));
+    if (hipMalloc((void**)&b, bytes) != hipSuccess) { (void)hipFree(a); return fail(FDR_ERR_ALLOC, "fdr_dft_naive_c2c: hipMalloc"); }
+    hipError_t e = hipMemcpy(a, data_host, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_dft_naive(a, b, n, inverse, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(data_host, b, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(a); (void)hipFree(b);
+    FDR_HIP(e);
+    return FDR_OK;
+}
+
+int fdr_fft1d_c2c(float* data_host, int n, int inverse, int mode) {
+    if (!data_host || n < 0) return fail(FDR_ERR_ARG, "fdr_fft1d_c2c: bad argument");
+    if (mode != FDR_MODE_PARITY && mode != FDR_MODE_FAST) return fail(FDR_ERR_ARG, "fdr_fft1d_c2c: unknown mode");
+    if (n <= 1) return FDR_OK;                                        // fft/fft_serial.cpp:43
+    if (!fdr_is_pow2(n)) return fdr_dft_naive_c2c(data_host, n, inverse);  // fft/fft_serial.cpp:100-101
+    if (n > 8192) return fail(FDR_ERR_ARG, "fdr_fft1d_c2c: power-of-two length above 8192 (one row must fit LDS)");
+    std::vector<float2> t;
+    build_twiddles(n, mode, inverse != 0, t);
+    float2 *tw = nullptr, *d = nullptr;
+    const size_t bytes = (size_t)n * sizeof(float2);
+    FDR_HIP(hipMalloc((void**)&tw, t.size() * sizeof(float2)));
+    if (hipMalloc((void**)&d, bytes) != hipSuccess) { (void)hipFree(tw); return fail(FDR_ERR_ALLOC, "fdr_fft1d_c2c: hipMalloc"); }
+    hipError_t e = hipMemcpy(tw, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d, data_host, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const int logn = ilog2(n);
+        if (n >= 8) {
+            RowArgs ra{};
+            ra.src_c = d; ra.dst_c = d; ra.M = 1;
+            e = launch_rows(logn, mode, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, ra, tw, nullptr);
+        } else {
+            e = launch_simple_rows(d, 1, n, logn, tw, mode, nullptr);
+        }
+    }
+    if (e == hipSuccess) e = hipMemcpy(data_host, d, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(tw); (void)hipFree(d);
+    FDR_HIP(e);
+    return FDR_OK;
+}
+
+int fdr_synth_image_dev(int device, uint64_t seed, uint64_t first_index, size_t count, float* d_out, void* stream) {
+    if (!d_out && count) return fail(FDR_ERR_ARG, "fdr_synth_image_dev: null output");
+    FDR_HIP(hipSetDevice(device));
+    FDR_HIP(launch_synth(seed, first_index, count, d_out, (hipStream_t)stream));
+    return FDR_OK;
+}
+
+int fdr_plan_profile(fdr_plan* p, int enable) {
+    if (!p) return fail(FDR_ERR_ARG, "fdr_plan_profile: null plan");
+    FDR_HIP(hipSetDevice(p->device));
+    p->timer.reset();
+    p->timer.enabled = enable != 0;
+    return FDR_OK;
+}
+
+int fdr_plan_pass_times(fdr_plan* p, int* n_passes, float* mean_ms, const char** names, int* launches) {
+    if (!p || !n_passes) return fail(FDR_ERR_ARG, "fdr_plan_pass_times: null argument");
+    FDR_HIP(hipSetDevice(p->device));
+    double sum[FDR_MAX_PASSES] = {0};
+    int cnt[FDR_MAX_PASSES] = {0};
+    for (auto& r : p->timer.recs) {
+        FDR_HIP(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        FDR_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        sum[r.pass] += ms;
+        cnt[r.pass] += 1;
+    }
+    *n_passes = p->timer.n_names;
+    for (int i = 0; i < p->timer.n_names; ++i) {
+        if (mean_ms) mean_ms[i] = cnt[i] ? (float)(sum[i] / cnt[i]) : 0.f;
+        if (names) names[i] = p->timer.names[i];
+        if (launches) launches[i] = cnt[i];
+    }
+    p->timer.reset();
+    return FDR_OK;
+}
+
+}  // extern "C"

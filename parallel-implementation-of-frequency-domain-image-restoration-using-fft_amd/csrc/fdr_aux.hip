@@ -1,0 +1,308 @@
+// fdr_aux.hip -- auxiliary kernels: PSF generation, normalisation, synthetic input, the
+// Wiener filter construction, the O(n^2) DFT, and the reference-shaped "simple path"
+// (pad -> row FFT -> transpose -> row FFT -> transpose, fft/fft_gpu.cu:214-240) that serves as an
+// on-device cross-check and as the fallback for dimensions below 8.
+#include "fdr_fft_core.hpp"
+#include "fdr_kernels.hpp"
+
+namespace fdr {
+
+// ---- preprocess_kernel equivalent (fft/fft_gpu.cu:85-103): real -> complex with zero padding ----
+__global__ void pad_real_to_complex_kernel(const float* __restrict__ src, int rows, int cols, int stride,
+                                           float2* __restrict__ dst, int M, int N, unsigned* mm_init) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (mm_init != nullptr && x == 0 && y == 0) { mm_init[0] = 0xFFFFFFFFu; mm_init[1] = 0u; }
+    if (x < N && y < M) {
+        float p = 0.f;
+        if (x < cols && y < rows) p = src[(size_t)y * stride + x];
+        dst[(size_t)y * N + x] = make_float2(p, 0.f);
+    }
+}
+
+hipError_t launch_pad_real_to_complex(const float* src, int rows, int cols, int stride, float2* dst, int M, int N,
+                                      unsigned* mm_init, hipStream_t s) {
+    const dim3 block(64, 4), grid((N + 63) / 64, (M + 3) / 4);
+    hipLaunchKernelGGL(pad_real_to_complex_kernel, grid, block, 0, s, src, rows, cols, stride, dst, M, N, mm_init);
+    return hipGetLastError();
+}
+
+// ---- reference-shaped row FFT: whole row in LDS, explicit bit reversal, one radix-2 stage per
+// barrier, flat butterfly index k (the shape of fft/fft_gpu.cu:108-148) but with the per-stage
+// table so that parity mode reproduces fft/fft_serial.cpp:53-66 bit for bit.
+template <class Pol>
+__global__ void simple_rows_kernel(float2* __restrict__ data, int rows, int L, int logl, const float2* __restrict__ tw) {
+    extern __shared__ float2 s_data[];
+    const int row = blockIdx.x;
+    if (row >= rows) return;
+    float2* p = data + (size_t)row * L;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        const int rev = logl ? (int)(__brev((unsigned)i) >> (32 - logl)) : 0;
+        s_data[rev] = p[i];
+    }
+    __syncthreads();
+    for (int len = 2; len <= L; len <<= 1) {
+        const int half = len >> 1;
+        for (int k = threadIdx.x; k < (L >> 1); k += blockDim.x) {
+            const int off = k & (half - 1);
+            const int ui = ((k - off) << 1) + off, vi = ui + half;
+            float2 u = s_data[ui], v = s_data[vi];
+            Pol::bfly(u, v, tw[(half - 1) + off]);
+            s_data[ui] = u;
+            s_data[vi] = v;
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < L; i += blockDim.x) p[i] = s_data[i];
+}
+
+hipError_t launch_simple_rows(float2* data, int rows, int L, int logl, const float2* tw, int mode, hipStream_t s) {
+    const size_t smem = (size_t)L * sizeof(float2);
+    int threads = L / 2;
+    if (threads < 64) threads = 64;
+    if (threads > 1024) threads = 1024;
+    if (smem > 48 * 1024) {  // opt in once to a 64 KiB dynamic LDS row (the reference never does)
+        static bool opted = false;
+        if (!opted) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&simple_rows_kernel<PolicyParity>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&simple_rows_kernel<PolicyFast>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            if (e != hipSuccess) return e;
+            opted = true;
+        }
+    }
+    if (mode == 0)
+        hipLaunchKernelGGL(simple_rows_kernel<PolicyParity>, dim3(rows), dim3(threads), smem, s, data, rows, L, logl, tw);
+    else
+        hipLaunchKernelGGL(simple_rows_kernel<PolicyFast>, dim3(rows), dim3(threads), smem, s, data, rows, L, logl, tw);
+    return hipGetLastError();
+}
+
+// ---- tile transpose through LDS (fft/fft_gpu.cu:153-164), 64-lane friendly 32x32 tile, +1 pad ----
+__global__ void transpose_kernel(const float2* __restrict__ src, float2* __restrict__ dst, int rows, int cols) {
+    __shared__ float2 tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    int x = blockIdx.x * 32 + tx;
+    for (int j = ty; j < 32; j += 8) {
+        const int y = blockIdx.y * 32 + j;
+        if (x < cols && y < rows) tile[j][tx] = src[(size_t)y * cols + x];
+    }
+    __syncthreads();
+    x = blockIdx.y * 32 + tx;
+    for (int j = ty; j < 32; j += 8) {
+        const int y = blockIdx.x * 32 + j;
+        if (x < rows && y < cols) dst[(size_t)y * rows + x] = tile[tx][j];
+    }
+}
+
+hipError_t launch_transpose(const float2* src, float2* dst, int rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, s, src, dst, rows, cols);
+    return hipGetLastError();
+}
+
+// ---- Wiener quotient, pointwise (simple path); parity: fft/fft_serial.cpp:186-224 op order ----
+__global__ void wiener_pointwise_kernel(float2* __restrict__ g, const float2* __restrict__ filt, size_t count, float K,
+                                        int mode) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float2 G = g[i], h = filt[i];
+    float2 o;
+    if (mode == 0) {
+        const float hr2 = h.x * h.x, hi2 = h.y * h.y;
+        const float mag = sqrtf(hr2 + hi2);
+        const float mag2 = mag * mag;
+        const float denom = mag2 + K;
+        const float chi = -h.y;
+        const float p0 = G.x * h.x, p1 = G.y * chi, p2 = G.x * chi, p3 = G.y * h.x;
+        const float nr = p0 - p1, ni = p2 + p3;
+        o.x = denom != 0.0f ? nr / denom : 0.0f;
+        o.y = denom != 0.0f ? ni / denom : 0.0f;
+    } else {
+        o.x = __builtin_fmaf(G.x, h.x, -(G.y * h.y));
+        o.y = __builtin_fmaf(G.x, h.y, G.y * h.x);
+    }
+    g[i] = o;
+}
+
+hipError_t launch_wiener_pointwise(float2* g, const float2* filt, size_t count, float K, int mode, hipStream_t s) {
+    hipLaunchKernelGGL(wiener_pointwise_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, g, filt, count, K,
+                       mode);
+    return hipGetLastError();
+}
+
+// ---- fast mode: W = conj(H) / (|H|^2 + K), evaluated in double, rounded once ----
+__global__ void make_filter_fast_kernel(const float2* __restrict__ H, float2* __restrict__ W, size_t count, float K) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float2 h = H[i];
+    const double hr = h.x, hi = h.y;
+    const double denom = hr * hr + hi * hi + (double)K;
+    float2 w = make_float2(0.f, 0.f);
+    if (denom != 0.0) { w.x = (float)(hr / denom); w.y = (float)(-hi / denom); }
+    W[i] = w;
+}
+
+hipError_t launch_make_filter_fast(const float2* H, float2* W, size_t count, float K, hipStream_t s) {
+    hipLaunchKernelGGL(make_filter_fast_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, H, W, count, K);
+    return hipGetLastError();
+}
+
+// ---- simple path: real plane + min/max (postprocess_kernel, fft/fft_gpu.cu:187-201, unscaled) ----
+__global__ void real_minmax_kernel(const float2* __restrict__ src, float* __restrict__ dst, int M, int N, int mm_rows,
+                                   int mm_cols, unsigned* mm) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    if (x < N && y < M) {
+        const float r = src[(size_t)y * N + x].x;
+        dst[(size_t)y * N + x] = r;
+        if (y < mm_rows && x < mm_cols) { mn = r; mx = r; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, off));
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+    }
+    if ((threadIdx.x & 63) == 0 && mn <= mx) {
+        atomicMin(&mm[0], float_key(mn));
+        atomicMax(&mm[1], float_key(mx));
+    }
+}
+
+hipError_t launch_real_minmax(const float2* src, float* dst, int M, int N, int mm_rows, int mm_cols, unsigned* mm,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(real_minmax_kernel, dim3((N + 255) / 256, M), dim3(256), 0, s, src, dst, M, N, mm_rows, mm_cols, mm);
+    return hipGetLastError();
+}
+
+// ---- cv::normalize(src, dst, 0, 1, NORM_MINMAX) (fft/fft_serial.cpp:246) + crop (serial.cpp:38) ----
+// scale/shift exactly as OpenCV 4.x derives them for CV_32F: double min/max, scale rounded to
+// float, shift = (float)dmin - (float)(smin*scale); applied as a float multiply then a float add.
+__global__ void normalize_kernel(const float* __restrict__ raw, int N, const unsigned* __restrict__ mm,
+                                 float* __restrict__ out, int rows, int cols, int out_stride) {
+    const double smin = (double)key_float(mm[0]), smax = (double)key_float(mm[1]);
+    double scale = ((smax - smin) > 2.2204460492503131e-16) ? 1.0 / (smax - smin) : 0.0;
+    scale = (double)(float)scale;
+    const float fscale = (float)scale;
+    const float fshift = 0.0f - (float)(smin * scale);
+    const int y = blockIdx.y;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < cols; x += gridDim.x * blockDim.x) {
+        const float p = raw[(size_t)y * N + x] * fscale;
+        out[(size_t)y * out_stride + x] = p + fshift;
+    }
+}
+
+hipError_t launch_normalize(const float* raw, int N, const unsigned* mm, float* out, int rows, int cols, int out_stride,
+                            int /*mode*/, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    int gx = (cols + 255) / 256;
+    if (gx > 16) gx = 16;
+    hipLaunchKernelGGL(normalize_kernel, dim3(gx, rows), dim3(256), 0, s, raw, N, mm, out, rows, cols, out_stride);
+    return hipGetLastError();
+}
+
+// ---- utils.hpp:15-24 motionBlurKernel on the device ----
+// The source kernel (row size/2 set to 1/size) is analytic; the inverse affine map is prepared on
+// the host in double exactly as cv::getRotationMatrix2D + cv::warpAffine do, and each destination
+// pixel replays WarpAffineInvoker's 10-bit fixed-point coordinates and remapBilinear's 32x32
+// float weights with BORDER_CONSTANT 0.
+struct PsfMap { double m[6]; };
+
+__device__ __forceinline__ int cv_round_dev(double v) {
+    if (v >= 2147483647.0) return 2147483647;
+    if (v <= -2147483648.0) return (-2147483647 - 1);
+    return __double2int_rn(v);
+}
+
+__global__ void psf_motion_kernel(int size, PsfMap map, float* __restrict__ out) {
+    const float line = (float)(1.0 / (double)size);
+    const int cy = size / 2;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < size * size; idx += gridDim.x * blockDim.x) {
+        const int y = idx / size, x = idx % size;
+        const int X0 = cv_round_dev((map.m[1] * y + map.m[2]) * 1024.0) + 16;
+        const int Y0 = cv_round_dev((map.m[4] * y + map.m[5]) * 1024.0) + 16;
+        const int adelta = cv_round_dev(map.m[0] * x * 1024.0), bdelta = cv_round_dev(map.m[3] * x * 1024.0);
+        const int X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+        const int sx = X >> 5, sy = Y >> 5, ax = X & 31, ay = Y & 31;
+        const float fx = ax * (1.f / 32.f), fy = ay * (1.f / 32.f);
+        const float vx0 = 1.f - fx, vx1 = fx, vy0 = 1.f - fy, vy1 = fy;
+        const float w0 = vy0 * vx0, w1 = vy0 * vx1, w2 = vy1 * vx0, w3 = vy1 * vx1;
+        const bool x0in = sx >= 0 && sx < size, x1in = sx + 1 >= 0 && sx + 1 < size;
+        const float s00 = (sy == cy && x0in) ? line : 0.f, s01 = (sy == cy && x1in) ? line : 0.f;
+        const float s10 = (sy + 1 == cy && x0in) ? line : 0.f, s11 = (sy + 1 == cy && x1in) ? line : 0.f;
+        const float t0 = s00 * w0, t1 = s01 * w1, t2 = s10 * w2, t3 = s11 * w3;
+        float acc = t0 + t1;
+        acc = acc + t2;
+        acc = acc + t3;
+        out[idx] = acc;
+    }
+}
+
+hipError_t launch_psf_motion(int size, double angle_deg, float* d_out, hipStream_t s) {
+    const double PI = 3.1415926535897932384626433832795;
+    const double a = angle_deg * PI / 180.0;
+    const double alpha = cos(a), beta = sin(a);
+    const double cx = (double)(float)(size / 2), cy = (double)(float)(size / 2);
+    double M[6] = {alpha, beta, (1 - alpha) * cx - beta * cy, -beta, alpha, beta * cx + (1 - alpha) * cy};
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1. / D : 0;
+    const double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11; M[1] *= -D; M[3] *= -D; M[4] = A22;
+    const double b1 = -M[0] * M[2] - M[1] * M[5];
+    const double b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+    PsfMap map;
+    for (int i = 0; i < 6; ++i) map.m[i] = M[i];
+    int blocks = (size * size + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(psf_motion_kernel, dim3(blocks), dim3(256), 0, s, size, map, d_out);
+    return hipGetLastError();
+}
+
+// ---- counter-based synthetic image: top 24 bits of splitmix64(seed + first + i) / 2^24 ----
+__global__ void synth_kernel(uint64_t seed, uint64_t first, size_t count, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t x = seed + first + i;
+        x += 0x9E3779B97F4A7C15ULL;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+        x = x ^ (x >> 31);
+        out[i] = (float)(x >> 40) * (1.0f / 16777216.0f);
+    }
+}
+
+hipError_t launch_synth(uint64_t seed, uint64_t first, size_t count, float* d_out, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(synth_kernel, dim3((unsigned)blocks), dim3(256), 0, s, seed, first, count, d_out);
+    return hipGetLastError();
+}
+
+// ---- fft_serial::dft_naive_inplace (fft/fft_serial.cpp:71-87): one thread per output k, terms
+// accumulated in the reference's order t = 0..n-1; angle evaluated in double, rounded to float.
+__global__ void dft_naive_kernel(const float2* __restrict__ src, float2* __restrict__ dst, int n, int inverse) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double sign = inverse ? 1.0 : -1.0;
+    float sr = 0.f, si = 0.f;
+    for (int t = 0; t < n; ++t) {
+        const float ang = (float)(2.0 * 3.1415926535897932384626433832795 * (double)k * (double)t / (double)n * sign);
+        const float wr = cosf(ang), wi = sinf(ang);
+        const float2 a = src[t];
+        const float pr = a.x * wr - a.y * wi, pi = a.x * wi + a.y * wr;
+        sr += pr;
+        si += pi;
+    }
+    dst[k] = make_float2(sr, si);
+}
+
+hipError_t launch_dft_naive(const float2* src, float2* dst, int n, int inverse, hipStream_t s) {
+    hipLaunchKernelGGL(dft_naive_kernel, dim3((n + 127) / 128), dim3(128), 0, s, src, dst, n, inverse);
+    return hipGetLastError();
+}
+
+}  // namespace fdr

@@ -1,0 +1,244 @@
+// fdr_cols.hip -- column passes without a transpose: a thread group keeps B = 4 adjacent columns
+// (32 contiguous bytes per row) entirely in registers, 8 values per column per thread, and uses
+// LDS only as the inter-step exchange stage (two alternating buffers, one barrier per column).
+// This replaces transpose_kernel_opt + fft_row_optimized_kernel + transpose_kernel_opt of the
+// reference (fft/fft_gpu.cu:153-164, 214-240) and, in fast mode, also wiener_kernel (:169-181).
+//
+// A 128-byte line of the row-major M x N array is shared by 16/(4*G) workgroups; the tile map
+// below places those workgroups on the same XCD (blocks b, b+8, b+16.. share an L2) so the line
+// is fetched from / written back to the memory side once.  This only affects speed.
+#include "fdr_fft_core.hpp"
+#include "fdr_kernels.hpp"
+
+namespace fdr {
+
+template <int LOGM>
+struct ColGeom {
+    static constexpr int T = Steps<LOGM>::T;
+    static constexpr int B = 4;                                      // columns per thread group
+    static constexpr int G = T >= 512 ? 1 : (T >= 256 ? 2 : 4);      // thread groups per workgroup
+    static constexpr int THREADS = T * G;
+    static constexpr int COLS = B * G;                               // columns per workgroup
+    static constexpr int SHARE = 16 / COLS;                          // workgroups per 128-byte line
+};
+
+__device__ __forceinline__ int col_tile_of_block(int b, int ntiles, int share) {
+    if (share <= 1 || (ntiles % (8 * share)) != 0) return b;
+    const int grp = b / (8 * share), r = b % (8 * share);
+    return grp * 8 * share + (r % 8) * share + (r / 8);
+}
+
+__device__ __forceinline__ void load4(const float2* p, float2& a, float2& b, float2& c, float2& d) {
+    const float4 lo = *reinterpret_cast<const float4*>(p);
+    const float4 hi = *reinterpret_cast<const float4*>(p + 2);
+    a = make_float2(lo.x, lo.y); b = make_float2(lo.z, lo.w);
+    c = make_float2(hi.x, hi.y); d = make_float2(hi.z, hi.w);
+}
+__device__ __forceinline__ void store4(float2* p, float2 a, float2 b, float2 c, float2 d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a.x, a.y, b.x, b.y);
+    *reinterpret_cast<float4*>(p + 2) = make_float4(c.x, c.y, d.x, d.y);
+}
+
+// fft/fft_serial.cpp:186-224 in the reference's operation order, every op rounded separately:
+// mag = sqrt(Hr^2 + Hi^2); denom = mag*mag + K; num = G * conj(H); out = num / denom.
+__device__ __forceinline__ float2 wiener_parity(float2 g, float2 h, float K) {
+    const float hr2 = h.x * h.x, hi2 = h.y * h.y;
+    const float mag = sqrtf(hr2 + hi2);
+    const float mag2 = mag * mag;
+    const float denom = mag2 + K;
+    const float chi = -h.y;
+    const float p0 = g.x * h.x, p1 = g.y * chi, p2 = g.x * chi, p3 = g.y * h.x;
+    const float nr = p0 - p1, ni = p2 + p3;
+    float2 o;
+    o.x = denom != 0.0f ? nr / denom : 0.0f;  // cv::divide yields 0 on a zero divisor
+    o.y = denom != 0.0f ? ni / denom : 0.0f;
+    return o;
+}
+__device__ __forceinline__ float2 cmul_fma(float2 a, float2 w) {
+    return make_float2(__builtin_fmaf(a.x, w.x, -(a.y * w.y)), __builtin_fmaf(a.x, w.y, a.y * w.x));
+}
+
+__device__ __forceinline__ void block_minmax_commit_cols(float mn, float mx, unsigned* mm) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, off));
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+    }
+    if ((threadIdx.x & 63) == 0 && mn <= mx) {
+        atomicMin(&mm[0], float_key(mn));
+        atomicMax(&mm[1], float_key(mx));
+    }
+}
+
+template <int LOGM, class Pol, int KIND>
+__global__ __launch_bounds__(ColGeom<LOGM>::THREADS) void fft_cols_kernel(const ColArgs a, const float2* __restrict__ tw_fwd,
+                                                                          const float2* __restrict__ tw_inv) {
+    using St = Steps<LOGM>;
+    using Geo = ColGeom<LOGM>;
+    constexpr int B = Geo::B, G = Geo::G, T = St::T;
+    using Core = FftCore<LOGM, B, 2, Pol>;
+    __shared__ float2 lds[G * 2 * St::BUF];
+
+    const int N = a.N;
+    const int ntiles = (N + Geo::COLS - 1) / Geo::COLS;
+    const int tile = col_tile_of_block(blockIdx.x, ntiles, Geo::SHARE);
+    const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
+    const int col0 = (tile * G + g) * B;
+    const bool active = col0 < N;  // N is a multiple of 4 on this path
+    float2* grp_lds = lds + g * 2 * St::BUF;
+
+    float2 v[B][8];
+#pragma unroll
+    for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+        for (int q = 0; q < Core::RHO0; ++q) {
+            const int m = Core::in_index(tid, u, q);
+            const int s = u * Core::RHO0 + q;
+            if (active) load4(a.data + (size_t)m * N + col0, v[0][s], v[1][s], v[2][s], v[3][s]);
+            else v[0][s] = v[1][s] = v[2][s] = v[3][s] = make_float2(0.f, 0.f);
+        }
+
+    constexpr bool kInverseOnly = (KIND == COL_INV || KIND == COL_INV_REAL);
+    Core::template run<0>(v, grp_lds, kInverseOnly ? tw_inv : tw_fwd, tid);
+
+    if (KIND == COL_FWD || KIND == COL_INV) {
+        if (active) {
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int s = u * Core::RHOL + q;
+                    store4(a.data + (size_t)Core::out_index(tid, u, q) * N + col0, v[0][s], v[1][s], v[2][s], v[3][s]);
+                }
+        }
+    } else if (KIND == COL_FWD_WIENER) {
+        if (active) {
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int s = u * Core::RHOL + q;
+                    const size_t off = (size_t)Core::out_index(tid, u, q) * N + col0;
+                    float2 h0, h1, h2, h3;
+                    load4(a.filt + off, h0, h1, h2, h3);
+                    store4(a.data + off, wiener_parity(v[0][s], h0, a.K), wiener_parity(v[1][s], h1, a.K),
+                           wiener_parity(v[2][s], h2, a.K), wiener_parity(v[3][s], h3, a.K));
+                }
+        }
+    } else if (KIND == COL_INV_REAL) {
+        float mn = __builtin_inff(), mx = -__builtin_inff();
+        if (active) {
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int s = u * Core::RHOL + q;
+                    const int m = Core::out_index(tid, u, q);
+                    const float4 r = make_float4(v[0][s].x, v[1][s].x, v[2][s].x, v[3][s].x);
+                    *reinterpret_cast<float4*>(a.dst_real + (size_t)m * N + col0) = r;
+                    if (m < a.mm_rows) {
+                        if (col0 + 0 < a.mm_cols) { mn = fminf(mn, r.x); mx = fmaxf(mx, r.x); }
+                        if (col0 + 1 < a.mm_cols) { mn = fminf(mn, r.y); mx = fmaxf(mx, r.y); }
+                        if (col0 + 2 < a.mm_cols) { mn = fminf(mn, r.z); mx = fmaxf(mx, r.z); }
+                        if (col0 + 3 < a.mm_cols) { mn = fminf(mn, r.w); mx = fmaxf(mx, r.w); }
+                    }
+                }
+        }
+        block_minmax_commit_cols(mn, mx, a.mm);
+    } else {  // COL_FUSED
+        // multiply by the precomputed Wiener filter W = conj(H) / (|H|^2 + K) at the output rows
+#pragma unroll
+        for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+            for (int q = 0; q < Core::RHOL; ++q) {
+                const int s = u * Core::RHOL + q;
+                if (active) {
+                    float2 w0, w1, w2, w3;
+                    load4(a.filt + (size_t)Core::out_index(tid, u, q) * N + col0, w0, w1, w2, w3);
+                    v[0][s] = cmul_fma(v[0][s], w0);
+                    v[1][s] = cmul_fma(v[1][s], w1);
+                    v[2][s] = cmul_fma(v[2][s], w2);
+                    v[3][s] = cmul_fma(v[3][s], w3);
+                }
+            }
+        constexpr int SEQ1 = Core::SLOTS;
+        if constexpr (Core::RHOL != Core::RHO0) {
+            // the last forward step left X[(t + T u) + (L/RHOL) q]; the first inverse step wants
+            // x[(t + T u') + (L/RHO0) q'].  Both index sets are contiguous in t: one natural-order
+            // LDS round trip per column, no padding needed.
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                float2* buf = grp_lds + ((SEQ1 + b) & 1) * St::BUF;
+#pragma unroll
+                for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                    for (int q = 0; q < Core::RHOL; ++q) buf[Core::out_index(tid, u, q)] = v[b][u * Core::RHOL + q];
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+                    for (int q = 0; q < Core::RHO0; ++q) v[b][u * Core::RHO0 + q] = buf[Core::in_index(tid, u, q)];
+            }
+            Core::template run<SEQ1 + B>(v, grp_lds, tw_inv, tid);
+        } else {
+            Core::template run<SEQ1>(v, grp_lds, tw_inv, tid);
+        }
+        if (active) {
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int s = u * Core::RHOL + q;
+                    store4(a.data + (size_t)Core::out_index(tid, u, q) * N + col0, v[0][s], v[1][s], v[2][s], v[3][s]);
+                }
+        }
+    }
+}
+
+template <int LOGM, class Pol, int KIND>
+static hipError_t launch_cols_one(const ColArgs& a, const float2* twf, const float2* twi, hipStream_t s) {
+    using Geo = ColGeom<LOGM>;
+    const int ntiles = (a.N + Geo::COLS - 1) / Geo::COLS;
+    hipLaunchKernelGGL((fft_cols_kernel<LOGM, Pol, KIND>), dim3(ntiles), dim3(Geo::THREADS), 0, s, a, twf, twi);
+    return hipGetLastError();
+}
+
+template <int LOGM>
+static hipError_t launch_cols_kind(int mode, ColKind kind, const ColArgs& a, const float2* twf, const float2* twi,
+                                   hipStream_t s) {
+    if (mode == 0) {
+        switch (kind) {
+            case COL_FWD: return launch_cols_one<LOGM, PolicyParity, COL_FWD>(a, twf, twi, s);
+            case COL_INV: return launch_cols_one<LOGM, PolicyParity, COL_INV>(a, twf, twi, s);
+            case COL_FWD_WIENER: return launch_cols_one<LOGM, PolicyParity, COL_FWD_WIENER>(a, twf, twi, s);
+            case COL_INV_REAL: return launch_cols_one<LOGM, PolicyParity, COL_INV_REAL>(a, twf, twi, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    switch (kind) {
+        case COL_FWD: return launch_cols_one<LOGM, PolicyFast, COL_FWD>(a, twf, twi, s);
+        case COL_INV: return launch_cols_one<LOGM, PolicyFast, COL_INV>(a, twf, twi, s);
+        case COL_FUSED: return launch_cols_one<LOGM, PolicyFast, COL_FUSED>(a, twf, twi, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_cols(int logm, int mode, ColKind kind, const ColArgs& a, const float2* twf, const float2* twi,
+                       hipStream_t s) {
+    switch (logm) {
+        case 3: return launch_cols_kind<3>(mode, kind, a, twf, twi, s);
+        case 4: return launch_cols_kind<4>(mode, kind, a, twf, twi, s);
+        case 5: return launch_cols_kind<5>(mode, kind, a, twf, twi, s);
+        case 6: return launch_cols_kind<6>(mode, kind, a, twf, twi, s);
+        case 7: return launch_cols_kind<7>(mode, kind, a, twf, twi, s);
+        case 8: return launch_cols_kind<8>(mode, kind, a, twf, twi, s);
+        case 9: return launch_cols_kind<9>(mode, kind, a, twf, twi, s);
+        case 10: return launch_cols_kind<10>(mode, kind, a, twf, twi, s);
+        case 11: return launch_cols_kind<11>(mode, kind, a, twf, twi, s);
+        case 12: return launch_cols_kind<12>(mode, kind, a, twf, twi, s);
+        case 13: return launch_cols_kind<13>(mode, kind, a, twf, twi, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace fdr

@@ -1,0 +1,64 @@
+// fdr_kernels.hpp -- argument blocks and launcher declarations shared between the kernel
+// translation units (compiled for gfx950 with -ffp-contract=off) and the host-side plan code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace fdr {
+
+enum RowIn { ROW_IN_REAL = 0, ROW_IN_COMPLEX = 1 };
+enum RowOut { ROW_OUT_COMPLEX = 0, ROW_OUT_REAL_MINMAX = 1 };
+enum ColKind {
+    COL_FWD = 0,         // forward column FFT, complex in place (PSF spectrum, fft2d)
+    COL_INV = 1,         // inverse column FFT, complex in place (fft2d)
+    COL_FWD_WIENER = 2,  // parity pass B: forward column FFT then the Wiener quotient against H
+    COL_INV_REAL = 3,    // parity pass D: inverse column FFT, real part to the raw plane, min/max
+    COL_FUSED = 4        // fast pass B': forward column FFT, multiply by W, inverse column FFT
+};
+
+struct RowArgs {
+    // input
+    const float* src_real;  // ROW_IN_REAL: rows x cols image, zero-padded on the fly to M x L
+    int src_rows, src_cols, src_stride;
+    const float2* src_c;  // ROW_IN_COMPLEX: M x L
+    // output
+    float2* dst_c;    // ROW_OUT_COMPLEX: M x L
+    float* dst_real;  // ROW_OUT_REAL_MINMAX: M x L real plane
+    unsigned* mm;     // two ordered keys {min, max}
+    int mm_rows, mm_cols;
+    unsigned* mm_init;  // if non-null, block 0 resets the keys (first pass of an image)
+    int M;              // number of rows to transform
+};
+
+struct ColArgs {
+    float2* data;        // M x N complex, transformed in place
+    const float2* filt;  // H (parity) or W (fast), M x N
+    float K;
+    float* dst_real;  // COL_INV_REAL: M x N real plane
+    unsigned* mm;
+    int mm_rows, mm_cols;
+    int N;  // row length (number of columns)
+};
+
+// launchers (fdr_rows.hip / fdr_cols.hip); logl = log2 of the transform length, 3..13
+hipError_t launch_rows(int logl, int mode, RowIn in, RowOut out, const RowArgs& a, const float2* tw, hipStream_t s);
+hipError_t launch_cols(int logm, int mode, ColKind kind, const ColArgs& a, const float2* tw_fwd, const float2* tw_inv,
+                       hipStream_t s);
+
+// reference-shaped and auxiliary kernels (fdr_aux.hip)
+hipError_t launch_pad_real_to_complex(const float* src, int rows, int cols, int stride, float2* dst, int M, int N,
+                                      unsigned* mm_init, hipStream_t s);
+hipError_t launch_simple_rows(float2* data, int rows, int L, int logl, const float2* tw, int mode, hipStream_t s);
+hipError_t launch_transpose(const float2* src, float2* dst, int rows, int cols, hipStream_t s);
+hipError_t launch_wiener_pointwise(float2* g, const float2* filt, size_t count, float K, int mode, hipStream_t s);
+hipError_t launch_make_filter_fast(const float2* H, float2* W, size_t count, float K, hipStream_t s);
+hipError_t launch_real_minmax(const float2* src, float* dst, int M, int N, int mm_rows, int mm_cols, unsigned* mm,
+                              hipStream_t s);
+hipError_t launch_normalize(const float* raw, int N, const unsigned* mm, float* out, int rows, int cols, int out_stride,
+                            int mode, hipStream_t s);
+hipError_t launch_psf_motion(int size, double angle_deg, float* d_out, hipStream_t s);
+hipError_t launch_synth(uint64_t seed, uint64_t first, size_t count, float* d_out, hipStream_t s);
+hipError_t launch_dft_naive(const float2* src, float2* dst, int n, int inverse, hipStream_t s);
+
+}  // namespace fdr

@@ -1,0 +1,135 @@
+// fdr_rows.hip -- row passes: one contiguous row of L complex values per thread group.
+//   pass A  : real image (zero-padded on load) -> row FFT -> complex      (replaces preprocess_kernel
+//             + fft_row_optimized_kernel of the reference, fft/fft_gpu.cu:85-103,108-148)
+//   pass C  : complex -> row (I)FFT -> complex
+//   pass C' : complex -> row IFFT -> real plane + running min/max          (fuses postprocess_kernel,
+//             fft/fft_gpu.cu:187-201, and the min/max half of cv::normalize)
+// Loads and stores are natural order and coalesced: thread t of a group touches elements
+// t + (L/rho) q, so each of the rho wave-level accesses is one contiguous sweep of the row.
+#include "fdr_fft_core.hpp"
+#include "fdr_kernels.hpp"
+
+namespace fdr {
+
+template <int LOGL>
+struct RowGeom {
+    static constexpr int T = Steps<LOGL>::T;
+    static constexpr int G = T >= 256 ? 1 : 256 / T;  // rows per workgroup
+    static constexpr int THREADS = T * G;
+};
+
+__device__ __forceinline__ void block_minmax_commit(float mn, float mx, unsigned* mm) {
+    // wave reduction (64 lanes), then one pair of atomics per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, off));
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (mn <= mx) {  // skips waves that saw no element (mn=+inf, mx=-inf)
+            atomicMin(&mm[0], float_key(mn));
+            atomicMax(&mm[1], float_key(mx));
+        }
+    }
+}
+
+template <int LOGL, class Pol, int IN, int OUT>
+__global__ __launch_bounds__(RowGeom<LOGL>::THREADS) void fft_rows_kernel(const RowArgs a, const float2* __restrict__ tw) {
+    using St = Steps<LOGL>;
+    using Core = FftCore<LOGL, 1, 1, Pol>;
+    constexpr int L = St::L, T = St::T, G = RowGeom<LOGL>::G;
+    __shared__ float2 lds[G * St::BUF];
+
+    const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
+    const int row = blockIdx.x * G + g;
+    const bool active = row < a.M;
+
+    if (IN == ROW_IN_REAL && a.mm_init != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.mm_init[0] = 0xFFFFFFFFu;
+        a.mm_init[1] = 0u;
+    }
+
+    float2 v[1][8];
+#pragma unroll
+    for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+        for (int q = 0; q < Core::RHO0; ++q) {
+            const int n = Core::in_index(tid, u, q);
+            float2 x = make_float2(0.f, 0.f);
+            if (IN == ROW_IN_REAL) {
+                if (active && row < a.src_rows && n < a.src_cols) x.x = a.src_real[(size_t)row * a.src_stride + n];
+            } else {
+                if (active) x = a.src_c[(size_t)row * L + n];
+            }
+            v[0][u * Core::RHO0 + q] = x;
+        }
+
+    Core::run(v, lds + g * St::BUF, tw, tid);
+
+    if (OUT == ROW_OUT_COMPLEX) {
+        if (active) {
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q)
+                    a.dst_c[(size_t)row * L + Core::out_index(tid, u, q)] = v[0][u * Core::RHOL + q];
+        }
+    } else {
+        float mn = __builtin_inff(), mx = -__builtin_inff();
+        if (active) {
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int n = Core::out_index(tid, u, q);
+                    const float r = v[0][u * Core::RHOL + q].x;
+                    a.dst_real[(size_t)row * L + n] = r;
+                    if (row < a.mm_rows && n < a.mm_cols) {
+                        mn = fminf(mn, r);
+                        mx = fmaxf(mx, r);
+                    }
+                }
+        }
+        block_minmax_commit(mn, mx, a.mm);
+    }
+}
+
+template <int LOGL, class Pol>
+static hipError_t launch_rows_io(RowIn in, RowOut out, const RowArgs& a, const float2* tw, hipStream_t s) {
+    constexpr int G = RowGeom<LOGL>::G, THREADS = RowGeom<LOGL>::THREADS;
+    const dim3 grid((a.M + G - 1) / G), block(THREADS);
+    if (in == ROW_IN_REAL && out == ROW_OUT_COMPLEX)
+        hipLaunchKernelGGL((fft_rows_kernel<LOGL, Pol, ROW_IN_REAL, ROW_OUT_COMPLEX>), grid, block, 0, s, a, tw);
+    else if (in == ROW_IN_COMPLEX && out == ROW_OUT_COMPLEX)
+        hipLaunchKernelGGL((fft_rows_kernel<LOGL, Pol, ROW_IN_COMPLEX, ROW_OUT_COMPLEX>), grid, block, 0, s, a, tw);
+    else if (in == ROW_IN_COMPLEX && out == ROW_OUT_REAL_MINMAX)
+        hipLaunchKernelGGL((fft_rows_kernel<LOGL, Pol, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX>), grid, block, 0, s, a, tw);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+template <int LOGL>
+static hipError_t launch_rows_mode(int mode, RowIn in, RowOut out, const RowArgs& a, const float2* tw, hipStream_t s) {
+    return mode == 0 ? launch_rows_io<LOGL, PolicyParity>(in, out, a, tw, s)
+                     : launch_rows_io<LOGL, PolicyFast>(in, out, a, tw, s);
+}
+
+hipError_t launch_rows(int logl, int mode, RowIn in, RowOut out, const RowArgs& a, const float2* tw, hipStream_t s) {
+    switch (logl) {
+        case 3: return launch_rows_mode<3>(mode, in, out, a, tw, s);
+        case 4: return launch_rows_mode<4>(mode, in, out, a, tw, s);
+        case 5: return launch_rows_mode<5>(mode, in, out, a, tw, s);
+        case 6: return launch_rows_mode<6>(mode, in, out, a, tw, s);
+        case 7: return launch_rows_mode<7>(mode, in, out, a, tw, s);
+        case 8: return launch_rows_mode<8>(mode, in, out, a, tw, s);
+        case 9: return launch_rows_mode<9>(mode, in, out, a, tw, s);
+        case 10: return launch_rows_mode<10>(mode, in, out, a, tw, s);
+        case 11: return launch_rows_mode<11>(mode, in, out, a, tw, s);
+        case 12: return launch_rows_mode<12>(mode, in, out, a, tw, s);
+        case 13: return launch_rows_mode<13>(mode, in, out, a, tw, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace fdr
