@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixels/s restored (FFT + Wiener + IFFT) on synthetic N x N fp32 images, MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--size 4096] [--batch 4] [--mode fast|parity]
+
+A "step" is one pass of the hot path (pad -> FFT2 -> Wiener -> IFFT2 -> real -> normalise -> crop)
+over one batch of `--batch` device-resident synthetic images per GPU.  Inputs and outputs stay in
+HBM; the PSF spectrum is prepared once per plan, outside the timed region.  N > 1: one process per
+GPU (torch.distributed / RCCL), independent images sharded by rank, no data-path collective, weak
+scaling (per-GPU batch fixed).  Rank 0 prints ONE JSON line.
+
+The JSON line also carries
+  roofline     : algorithmic bytes of the dominant kernel / its mean duration, measured with hipEvent
+                 pairs on the launch stream over a repetition of the same K steps (the timed region
+                 itself is left un-instrumented), against the 8 TB/s HBM peak;
+  cpu_baseline : the CPU oracle (oracle/, a restatement of the reference's serial path) timed on one
+                 host core on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "parallel-implementation-of-frequency-domain-image-restoration-using-fft_amd"
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+# algorithmic bytes per padded pixel of each pass
+PASS_BYTES = {
+    "A rows: pad+FFT (real->complex)": 12,
+    "B cols: FFT+Wiener": 24,
+    "C rows: IFFT (complex)": 16,
+    "D cols: IFFT+real+minmax": 12,
+    "B' cols: FFT*W*IFFT": 24,
+    "C' rows: IFFT+real+minmax": 12,
+    "E normalize+crop": 8,
+}
+PIPELINE_BYTES = {"fast": 56, "parity": 72}
+SEEDS = {1024: 0x5EED0002, 4096: 0x5EED0003, 8192: 0x5EED0004, 2048: 0x5EED0005}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=4096, help="synthetic image edge (power of two)")
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step")
+    ap.add_argument("--mode", choices=["fast", "parity"], default="fast")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=0, help="edge of the CPU-baseline sample (default: --size, capped at 4096)")
+    return ap.parse_args()
+
+
+def cpu_baseline(size):
+    """Oracle (kind 'port'), one thread, one size x size single-channel image."""
+    from oracle import oracle as o
+    o.build()
+    psf = o.motion_blur_kernel(50, 30.0)
+    img = o.synth_image(SEEDS.get(size, 0x5EED0000), 0, size * size).reshape(size, size)
+    t0 = time.perf_counter()
+    o.serial_channel(img, psf, 0.01)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(size * size / 1e6 / dt, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+        "sample": "1 image %dx%d fp32, PSF 50/30deg, K=0.01, oracle/fdr_oracle.c (gcc -O2, no FMA), %.2f s on 1 of %d host cores"
+                  % (size, size, dt, os.cpu_count() or 0),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        # convenience: re-launch under torch.distributed.run as a child (nothing has touched the GPU yet)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)]
+        cmd += sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import torch
+    fdr = importlib.import_module(PKG)  # raises if libfdr.so is missing: no CPU fallback
+    from importlib import import_module
+    batch_mod = import_module(PKG + ".batch")
+
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    comm = batch_mod.Comm(backend="nccl", device=dev)
+    rank, world = comm.rank, comm.world
+
+    S, B = args.size, args.batch
+    mode = fdr.MODE_FAST if args.mode == "fast" else fdr.MODE_PARITY
+    P = S * S
+    seed = SEEDS.get(S, 0x5EED0000)
+
+    plan = fdr.Plan(S, S, mode, device=local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    plan.set_psf_motion(50, 30.0, 0.01, stream=stream)  # PSF generated, padded and transformed on the device
+    imgs = torch.empty((B, S, S), dtype=torch.float32, device=dev)
+    outs = torch.empty((B, S, S), dtype=torch.float32, device=dev)
+    # image b of rank r is global image r*B + b of the counter-based generator (distinct per rank)
+    fdr.synth_image_dev(imgs.data_ptr(), B * P, seed, first_index=rank * B * P, device=local_rank, stream=stream)
+    torch.cuda.synchronize()
+
+    def step():
+        plan.wiener_batch_dev(imgs.data_ptr(), P, B, S, S, S, outs.data_ptr(), P, S, fdr.NORM_PADDED, stream=stream)
+
+    elapsed = batch_mod.timed_steps(comm, step, torch.cuda.synchronize, args.steps, args.warmup)
+
+    # ---- per-kernel durations: hipEvent pairs on the launch stream, same K steps again ----
+    plan.profile(True)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    passes = plan.pass_times()
+    plan.profile(False)
+
+    # ---- consistency check over RCCL (outside the timed region) ----
+    chk = float(outs.double().sum().item())
+    finite = bool(torch.isfinite(outs).all().item())
+    omin, omax = float(outs.min().item()), float(outs.max().item())
+    tot = comm.allreduce_sum([B * args.steps, chk, 1.0 if (finite and omin >= 0.0 and omax <= 1.0) else 0.0])
+
+    if rank == 0:
+        images = world * B * args.steps
+        value = images * P / 1e6 / elapsed
+        pipe_gbps = PIPELINE_BYTES[args.mode] * P * images / elapsed / 1e9
+        dom = max(passes, key=lambda t: t[1]) if passes else None
+        roofline = None
+        if dom:
+            name, ms, cnt = dom
+            alg = PASS_BYTES.get(name, 0) * P
+            achieved = alg / (ms * 1e-3) / 1e9
+            roofline = {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "kernel": name, "kernel_ms": round(ms, 5), "launches_timed": cnt,
+                "algorithmic_bytes_per_launch": alg,
+                "all_passes_ms": {n: round(m, 5) for n, m, _ in passes},
+                "pipeline": {"bytes_per_pixel": PIPELINE_BYTES[args.mode], "achieved": round(pipe_gbps, 1),
+                             "frac": round(pipe_gbps / HBM_PEAK_GBPS, 4)},
+            }
+            tfile = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tfile):
+                try:
+                    tj = json.load(open(tfile))
+                    key = "%s/%d" % (args.mode, S)
+                    if key in tj and name in tj[key]:
+                        roofline["traffic"] = tj[key][name]
+                except Exception:
+                    pass
+        line = {
+            "metric": "Mpixels/sec restored (FFT+Wiener+IFFT) at %dx%d fp32" % (S, S),
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%dx%d synthetic fp32, PSF len=50 angle=30, K=0.01, single channel, device-resident" % (S, S),
+                       "images_per_gpu_per_step": B, "mode": args.mode, "parallelism": "images sharded over %d rank(s)" % world,
+                       "normalize_area": "padded (serial semantics)"},
+            "roofline": roofline,
+            "check": {"images_done": int(tot[0]), "checksum": tot[1], "ranks_ok": int(tot[2])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cs = args.cpu_size or min(S, 4096)
+            line["cpu_baseline"] = cpu_baseline(cs)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+
+    plan.close()
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()

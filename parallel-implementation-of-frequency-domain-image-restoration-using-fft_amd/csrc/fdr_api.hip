@@ -111,7 +111,9 @@ struct fdr_plan {
     float* raw = nullptr;     // M x N real plane before normalisation
     float* psf_dev = nullptr; // staging for host-pointer / generated PSFs
     size_t psf_cap = 0;
-    unsigned* mm = nullptr;
+    float* mm = nullptr;       // final {min, max}
+    float2* mm_part = nullptr; // per-workgroup partials
+    int mm_part_cap = 0;
     float K = 0.f;
     bool have_psf = false;
     PassTimer timer;
@@ -175,7 +177,7 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
         return fail(FDR_ERR_ARG, "fdr_set_psf: PSF larger than the padded image (copyMakeBorder would throw, fft_serial.cpp:168)");
     // pad top-left + forward 2-D FFT (fft/fft_serial.cpp:166-171,182)
     if (p->simple) {
-        FDR_HIP(launch_pad_real_to_complex(d_psf, prows, pcols, pstride, p->filt, p->M, p->N, nullptr, s));
+        FDR_HIP(launch_pad_real_to_complex(d_psf, prows, pcols, pstride, p->filt, p->M, p->N, s));
         int rc = dft2d_dev(p, p->filt, false, s);
         if (rc != FDR_OK) return rc;
     } else {
@@ -203,22 +205,23 @@ int wiener_dev_impl(fdr_plan* p, const float* d_img, int rows, int cols, int str
     const int mm_rows = norm_area == FDR_NORM_PADDED ? p->M : rows;
     const int mm_cols = norm_area == FDR_NORM_PADDED ? p->N : cols;
     const size_t P = (size_t)p->M * p->N;
+    int n_part = 0;
 
     if (p->simple) {
         ScopedPass t(p, s, kPassSimple);
-        FDR_HIP(launch_pad_real_to_complex(d_img, rows, cols, stride, p->work, p->M, p->N, p->mm, s));
+        FDR_HIP(launch_pad_real_to_complex(d_img, rows, cols, stride, p->work, p->M, p->N, s));
         int rc = dft2d_dev(p, p->work, false, s);
         if (rc != FDR_OK) return rc;
         FDR_HIP(launch_wiener_pointwise(p->work, p->filt, P, p->K, p->mode, s));
         rc = dft2d_dev(p, p->work, true, s);
         if (rc != FDR_OK) return rc;
-        FDR_HIP(launch_real_minmax(p->work, p->raw, p->M, p->N, mm_rows, mm_cols, p->mm, s));
+        FDR_HIP(launch_real_minmax(p->work, p->raw, p->M, p->N, mm_rows, mm_cols, p->mm_part, &n_part, s));
     } else if (p->mode == FDR_MODE_PARITY) {
         {   // A: rows, real -> complex (fft/fft_serial.cpp:157-165,176 first half)
             ScopedPass t(p, s, kPassRowsFwd);
             RowArgs a{};
             a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
-            a.dst_c = p->work; a.M = p->M; a.mm_init = p->mm;
+            a.dst_c = p->work; a.M = p->M;
             FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
         }
         {   // B: columns forward + Wiener quotient (:176 second half, :186-224)
@@ -236,15 +239,16 @@ int wiener_dev_impl(fdr_plan* p, const float* d_img, int rows, int cols, int str
         {   // D: columns inverse, real plane, min/max (:229 second half, :236-240, minMaxIdx of :246)
             ScopedPass t(p, s, kPassColsInvReal);
             ColArgs c{};
-            c.data = p->work; c.dst_real = p->raw; c.mm = p->mm; c.mm_rows = mm_rows; c.mm_cols = mm_cols; c.N = p->N;
+            c.data = p->work; c.dst_real = p->raw; c.mm_part = p->mm_part; c.mm_rows = mm_rows; c.mm_cols = mm_cols; c.N = p->N;
             FDR_HIP(launch_cols(p->logM, p->mode, COL_INV_REAL, c, p->tw_col_f, p->tw_col_i, s));
+            n_part = cols_minmax_partials(p->logM, p->N);
         }
     } else {
         {   // A
             ScopedPass t(p, s, kPassRowsFwd);
             RowArgs a{};
             a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
-            a.dst_c = p->work; a.M = p->M; a.mm_init = p->mm;
+            a.dst_c = p->work; a.M = p->M;
             FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
         }
         {   // B': columns forward, multiply by W, columns inverse -- one HBM round trip
@@ -256,12 +260,15 @@ int wiener_dev_impl(fdr_plan* p, const float* d_img, int rows, int cols, int str
         {   // C': rows inverse, real plane, min/max
             ScopedPass t(p, s, kPassRowsInvReal);
             RowArgs a{};
-            a.src_c = p->work; a.dst_real = p->raw; a.mm = p->mm; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
+            a.src_c = p->work; a.dst_real = p->raw; a.mm_part = p->mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
             FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, a, p->tw_row_i, s));
+            n_part = rows_minmax_partials(p->logN, p->M);
         }
     }
     {   // E: normalise to [0,1] and crop (fft/fft_serial.cpp:246, serial.cpp:38)
         ScopedPass t(p, s, kPassNormalize);
+        if (n_part <= 0 || n_part > p->mm_part_cap) return fail(FDR_ERR_STATE, "fdr_wiener: min/max partial count out of range");
+        FDR_HIP(launch_reduce_minmax(p->mm_part, n_part, p->mm, s));
         FDR_HIP(launch_normalize(p->raw, p->N, p->mm, d_out, rows, cols, out_stride, p->mode, s));
     }
     return FDR_OK;
@@ -314,7 +321,8 @@ int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan
     if (hipMalloc((void**)&p->work, P * sizeof(float2)) != hipSuccess ||
         hipMalloc((void**)&p->filt, P * sizeof(float2)) != hipSuccess ||
         hipMalloc((void**)&p->raw, P * sizeof(float)) != hipSuccess ||
-        hipMalloc((void**)&p->mm, 2 * sizeof(unsigned)) != hipSuccess ||
+        hipMalloc((void**)&p->mm, 2 * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&p->mm_part, (size_t)(p->mm_part_cap = (int)(((size_t)N + 255) / 256 * M + 8192)) * sizeof(float2)) != hipSuccess ||
         (p->simple && hipMalloc((void**)&p->work2, P * sizeof(float2)) != hipSuccess)) {
         rc = fail(FDR_ERR_ALLOC, "fdr_plan_create: hipMalloc of the plan workspace failed");
         goto bad;
@@ -332,7 +340,7 @@ int fdr_plan_destroy(fdr_plan* p) {
     p->timer.destroy();
     (void)hipFree(p->tw_row_f); (void)hipFree(p->tw_row_i); (void)hipFree(p->tw_col_f); (void)hipFree(p->tw_col_i);
     (void)hipFree(p->work); (void)hipFree(p->work2); (void)hipFree(p->filt); (void)hipFree(p->raw);
-    (void)hipFree(p->psf_dev); (void)hipFree(p->mm);
+    (void)hipFree(p->psf_dev); (void)hipFree(p->mm); (void)hipFree(p->mm_part);
     delete p;
     return FDR_OK;
 }

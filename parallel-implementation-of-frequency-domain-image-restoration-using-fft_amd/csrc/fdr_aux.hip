@@ -9,10 +9,9 @@ namespace fdr {
 
 // ---- preprocess_kernel equivalent (fft/fft_gpu.cu:85-103): real -> complex with zero padding ----
 __global__ void pad_real_to_complex_kernel(const float* __restrict__ src, int rows, int cols, int stride,
-                                           float2* __restrict__ dst, int M, int N, unsigned* mm_init) {
+                                           float2* __restrict__ dst, int M, int N) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (mm_init != nullptr && x == 0 && y == 0) { mm_init[0] = 0xFFFFFFFFu; mm_init[1] = 0u; }
     if (x < N && y < M) {
         float p = 0.f;
         if (x < cols && y < rows) p = src[(size_t)y * stride + x];
@@ -21,9 +20,9 @@ __global__ void pad_real_to_complex_kernel(const float* __restrict__ src, int ro
 }
 
 hipError_t launch_pad_real_to_complex(const float* src, int rows, int cols, int stride, float2* dst, int M, int N,
-                                      unsigned* mm_init, hipStream_t s) {
+                                      hipStream_t s) {
     const dim3 block(64, 4), grid((N + 63) / 64, (M + 3) / 4);
-    hipLaunchKernelGGL(pad_real_to_complex_kernel, grid, block, 0, s, src, rows, cols, stride, dst, M, N, mm_init);
+    hipLaunchKernelGGL(pad_real_to_complex_kernel, grid, block, 0, s, src, rows, cols, stride, dst, M, N);
     return hipGetLastError();
 }
 
@@ -151,7 +150,7 @@ hipError_t launch_make_filter_fast(const float2* H, float2* W, size_t count, flo
 
 // ---- simple path: real plane + min/max (postprocess_kernel, fft/fft_gpu.cu:187-201, unscaled) ----
 __global__ void real_minmax_kernel(const float2* __restrict__ src, float* __restrict__ dst, int M, int N, int mm_rows,
-                                   int mm_cols, unsigned* mm) {
+                                   int mm_cols, float2* __restrict__ mm_part) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     float mn = __builtin_inff(), mx = -__builtin_inff();
@@ -160,29 +159,54 @@ __global__ void real_minmax_kernel(const float2* __restrict__ src, float* __rest
         dst[(size_t)y * N + x] = r;
         if (y < mm_rows && x < mm_cols) { mn = r; mx = r; }
     }
+    block_minmax_store(mn, mx, mm_part);
+}
+
+hipError_t launch_real_minmax(const float2* src, float* dst, int M, int N, int mm_rows, int mm_cols, float2* mm_part,
+                              int* n_part, hipStream_t s) {
+    const dim3 grid((N + 255) / 256, M);
+    *n_part = (int)(grid.x * grid.y);
+    hipLaunchKernelGGL(real_minmax_kernel, grid, dim3(256), 0, s, src, dst, M, N, mm_rows, mm_cols, mm_part);
+    return hipGetLastError();
+}
+
+// ---- final min/max over the per-workgroup partials: one workgroup, fixed order => deterministic ----
+__global__ void reduce_minmax_kernel(const float2* __restrict__ part, int n, float* __restrict__ mm) {
+    __shared__ float2 red[16];
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float2 p = part[i];
+        mn = fminf(mn, p.x);
+        mx = fmaxf(mx, p.y);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         mn = fminf(mn, __shfl_xor(mn, off));
         mx = fmaxf(mx, __shfl_xor(mx, off));
     }
-    if ((threadIdx.x & 63) == 0 && mn <= mx) {
-        atomicMin(&mm[0], float_key(mn));
-        atomicMax(&mm[1], float_key(mx));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = make_float2(mn, mx);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+            mn = fminf(mn, red[w].x);
+            mx = fmaxf(mx, red[w].y);
+        }
+        mm[0] = mn;
+        mm[1] = mx;
     }
 }
 
-hipError_t launch_real_minmax(const float2* src, float* dst, int M, int N, int mm_rows, int mm_cols, unsigned* mm,
-                              hipStream_t s) {
-    hipLaunchKernelGGL(real_minmax_kernel, dim3((N + 255) / 256, M), dim3(256), 0, s, src, dst, M, N, mm_rows, mm_cols, mm);
+hipError_t launch_reduce_minmax(const float2* mm_part, int n_part, float* mm, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_minmax_kernel, dim3(1), dim3(1024), 0, s, mm_part, n_part, mm);
     return hipGetLastError();
 }
 
 // ---- cv::normalize(src, dst, 0, 1, NORM_MINMAX) (fft/fft_serial.cpp:246) + crop (serial.cpp:38) ----
 // scale/shift exactly as OpenCV 4.x derives them for CV_32F: double min/max, scale rounded to
 // float, shift = (float)dmin - (float)(smin*scale); applied as a float multiply then a float add.
-__global__ void normalize_kernel(const float* __restrict__ raw, int N, const unsigned* __restrict__ mm,
+__global__ void normalize_kernel(const float* __restrict__ raw, int N, const float* __restrict__ mm,
                                  float* __restrict__ out, int rows, int cols, int out_stride) {
-    const double smin = (double)key_float(mm[0]), smax = (double)key_float(mm[1]);
+    const double smin = (double)mm[0], smax = (double)mm[1];
     double scale = ((smax - smin) > 2.2204460492503131e-16) ? 1.0 / (smax - smin) : 0.0;
     scale = (double)(float)scale;
     const float fscale = (float)scale;
@@ -194,7 +218,7 @@ __global__ void normalize_kernel(const float* __restrict__ raw, int N, const uns
     }
 }
 
-hipError_t launch_normalize(const float* raw, int N, const unsigned* mm, float* out, int rows, int cols, int out_stride,
+hipError_t launch_normalize(const float* raw, int N, const float* mm, float* out, int rows, int cols, int out_stride,
                             int /*mode*/, hipStream_t s) {
     if (rows <= 0 || cols <= 0) return hipSuccess;
     int gx = (cols + 255) / 256;

@@ -20,6 +20,8 @@ struct ColGeom {
     static constexpr int THREADS = T * G;
     static constexpr int COLS = B * G;                               // columns per workgroup
     static constexpr int SHARE = 16 / COLS;                          // workgroups per 128-byte line
+    // two 512-thread workgroups per CU (4 waves/SIMD) need <= 128 VGPRs; LDS (2 x 74 KB) allows it
+    static constexpr int WAVES_PER_SIMD = THREADS >= 512 ? 4 : 1;
 };
 
 __device__ __forceinline__ int col_tile_of_block(int b, int ntiles, int share) {
@@ -58,20 +60,8 @@ __device__ __forceinline__ float2 cmul_fma(float2 a, float2 w) {
     return make_float2(__builtin_fmaf(a.x, w.x, -(a.y * w.y)), __builtin_fmaf(a.x, w.y, a.y * w.x));
 }
 
-__device__ __forceinline__ void block_minmax_commit_cols(float mn, float mx, unsigned* mm) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        mn = fminf(mn, __shfl_xor(mn, off));
-        mx = fmaxf(mx, __shfl_xor(mx, off));
-    }
-    if ((threadIdx.x & 63) == 0 && mn <= mx) {
-        atomicMin(&mm[0], float_key(mn));
-        atomicMax(&mm[1], float_key(mx));
-    }
-}
-
 template <int LOGM, class Pol, int KIND>
-__global__ __launch_bounds__(ColGeom<LOGM>::THREADS) void fft_cols_kernel(const ColArgs a, const float2* __restrict__ tw_fwd,
+__global__ __launch_bounds__(ColGeom<LOGM>::THREADS, ColGeom<LOGM>::WAVES_PER_SIMD) void fft_cols_kernel(const ColArgs a, const float2* __restrict__ tw_fwd,
                                                                           const float2* __restrict__ tw_inv) {
     using St = Steps<LOGM>;
     using Geo = ColGeom<LOGM>;
@@ -144,7 +134,7 @@ __global__ __launch_bounds__(ColGeom<LOGM>::THREADS) void fft_cols_kernel(const 
                     }
                 }
         }
-        block_minmax_commit_cols(mn, mx, a.mm);
+        block_minmax_store(mn, mx, a.mm_part);
     } else {  // COL_FUSED
         // multiply by the precomputed Wiener filter W = conj(H) / (|H|^2 + K) at the output rows
 #pragma unroll
@@ -220,6 +210,26 @@ static hipError_t launch_cols_kind(int mode, ColKind kind, const ColArgs& a, con
         case COL_INV: return launch_cols_one<LOGM, PolicyFast, COL_INV>(a, twf, twi, s);
         case COL_FUSED: return launch_cols_one<LOGM, PolicyFast, COL_FUSED>(a, twf, twi, s);
         default: return hipErrorInvalidValue;
+    }
+}
+
+template <int LOGM>
+static int cols_partials(int N) { return (N + ColGeom<LOGM>::COLS - 1) / ColGeom<LOGM>::COLS; }
+
+int cols_minmax_partials(int logm, int N) {
+    switch (logm) {
+        case 3: return cols_partials<3>(N);
+        case 4: return cols_partials<4>(N);
+        case 5: return cols_partials<5>(N);
+        case 6: return cols_partials<6>(N);
+        case 7: return cols_partials<7>(N);
+        case 8: return cols_partials<8>(N);
+        case 9: return cols_partials<9>(N);
+        case 10: return cols_partials<10>(N);
+        case 11: return cols_partials<11>(N);
+        case 12: return cols_partials<12>(N);
+        case 13: return cols_partials<13>(N);
+        default: return 0;
     }
 }
 

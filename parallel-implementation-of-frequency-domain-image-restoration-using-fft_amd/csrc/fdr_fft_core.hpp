@@ -190,21 +190,28 @@ struct FftCore {
 };
 
 // ---------------------------------------------------------------------------------------------
-// order-preserving float <-> uint key for atomicMin/atomicMax based min/max reduction
+// min/max of the real plane: every producing workgroup writes ONE (min, max) partial; a single
+// small kernel reduces the partials (deterministic, and no same-address atomics: 65k atomics on
+// two words cost ~0.7 ms on MI355X, 15x the kernel that issued them).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned float_key(float f) {
-    const unsigned b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__host__ __device__ inline float key_float(unsigned k) {
-    const unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __uint_as_float(b);
-#else
-    float f;
-    __builtin_memcpy(&f, &b, 4);
-    return f;
-#endif
+__device__ __forceinline__ void block_minmax_store(float mn, float mx, float2* __restrict__ part) {
+    __shared__ float2 red[16];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, off));
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+    }
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) red[wave] = make_float2(mn, mx);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; ++w) {
+            mn = fminf(mn, red[w].x);
+            mx = fmaxf(mx, red[w].y);
+        }
+        const int b = blockIdx.x + gridDim.x * blockIdx.y;
+        part[b] = make_float2(mn, mx);  // (+inf, -inf) when the block saw no counted element
+    }
 }
 
 }  // namespace fdr

@@ -25,9 +25,8 @@ struct RowArgs {
     // output
     float2* dst_c;    // ROW_OUT_COMPLEX: M x L
     float* dst_real;  // ROW_OUT_REAL_MINMAX: M x L real plane
-    unsigned* mm;     // two ordered keys {min, max}
+    float2* mm_part;  // one (min, max) partial per workgroup
     int mm_rows, mm_cols;
-    unsigned* mm_init;  // if non-null, block 0 resets the keys (first pass of an image)
     int M;              // number of rows to transform
 };
 
@@ -36,7 +35,7 @@ struct ColArgs {
     const float2* filt;  // H (parity) or W (fast), M x N
     float K;
     float* dst_real;  // COL_INV_REAL: M x N real plane
-    unsigned* mm;
+    float2* mm_part;  // one (min, max) partial per workgroup
     int mm_rows, mm_cols;
     int N;  // row length (number of columns)
 };
@@ -48,14 +47,18 @@ hipError_t launch_cols(int logm, int mode, ColKind kind, const ColArgs& a, const
 
 // reference-shaped and auxiliary kernels (fdr_aux.hip)
 hipError_t launch_pad_real_to_complex(const float* src, int rows, int cols, int stride, float2* dst, int M, int N,
-                                      unsigned* mm_init, hipStream_t s);
+                                      hipStream_t s);
 hipError_t launch_simple_rows(float2* data, int rows, int L, int logl, const float2* tw, int mode, hipStream_t s);
 hipError_t launch_transpose(const float2* src, float2* dst, int rows, int cols, hipStream_t s);
 hipError_t launch_wiener_pointwise(float2* g, const float2* filt, size_t count, float K, int mode, hipStream_t s);
 hipError_t launch_make_filter_fast(const float2* H, float2* W, size_t count, float K, hipStream_t s);
-hipError_t launch_real_minmax(const float2* src, float* dst, int M, int N, int mm_rows, int mm_cols, unsigned* mm,
-                              hipStream_t s);
-hipError_t launch_normalize(const float* raw, int N, const unsigned* mm, float* out, int rows, int cols, int out_stride,
+hipError_t launch_real_minmax(const float2* src, float* dst, int M, int N, int mm_rows, int mm_cols, float2* mm_part,
+                              int* n_part, hipStream_t s);
+hipError_t launch_reduce_minmax(const float2* mm_part, int n_part, float* mm, hipStream_t s);
+// number of (min,max) partials the row / column real-output passes write for an M x N plan
+int rows_minmax_partials(int logl, int M);
+int cols_minmax_partials(int logm, int N);
+hipError_t launch_normalize(const float* raw, int N, const float* mm, float* out, int rows, int cols, int out_stride,
                             int mode, hipStream_t s);
 hipError_t launch_psf_motion(int size, double angle_deg, float* d_out, hipStream_t s);
 hipError_t launch_synth(uint64_t seed, uint64_t first, size_t count, float* d_out, hipStream_t s);

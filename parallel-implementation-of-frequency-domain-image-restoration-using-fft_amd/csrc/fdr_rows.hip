@@ -18,21 +18,6 @@ struct RowGeom {
     static constexpr int THREADS = T * G;
 };
 
-__device__ __forceinline__ void block_minmax_commit(float mn, float mx, unsigned* mm) {
-    // wave reduction (64 lanes), then one pair of atomics per wave
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        mn = fminf(mn, __shfl_xor(mn, off));
-        mx = fmaxf(mx, __shfl_xor(mx, off));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (mn <= mx) {  // skips waves that saw no element (mn=+inf, mx=-inf)
-            atomicMin(&mm[0], float_key(mn));
-            atomicMax(&mm[1], float_key(mx));
-        }
-    }
-}
-
 template <int LOGL, class Pol, int IN, int OUT>
 __global__ __launch_bounds__(RowGeom<LOGL>::THREADS) void fft_rows_kernel(const RowArgs a, const float2* __restrict__ tw) {
     using St = Steps<LOGL>;
@@ -43,11 +28,6 @@ __global__ __launch_bounds__(RowGeom<LOGL>::THREADS) void fft_rows_kernel(const 
     const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
     const int row = blockIdx.x * G + g;
     const bool active = row < a.M;
-
-    if (IN == ROW_IN_REAL && a.mm_init != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
-        a.mm_init[0] = 0xFFFFFFFFu;
-        a.mm_init[1] = 0u;
-    }
 
     float2 v[1][8];
 #pragma unroll
@@ -90,7 +70,7 @@ __global__ __launch_bounds__(RowGeom<LOGL>::THREADS) void fft_rows_kernel(const 
                     }
                 }
         }
-        block_minmax_commit(mn, mx, a.mm);
+        block_minmax_store(mn, mx, a.mm_part);
     }
 }
 
@@ -113,6 +93,26 @@ template <int LOGL>
 static hipError_t launch_rows_mode(int mode, RowIn in, RowOut out, const RowArgs& a, const float2* tw, hipStream_t s) {
     return mode == 0 ? launch_rows_io<LOGL, PolicyParity>(in, out, a, tw, s)
                      : launch_rows_io<LOGL, PolicyFast>(in, out, a, tw, s);
+}
+
+template <int LOGL>
+static int rows_partials(int M) { return (M + RowGeom<LOGL>::G - 1) / RowGeom<LOGL>::G; }
+
+int rows_minmax_partials(int logl, int M) {
+    switch (logl) {
+        case 3: return rows_partials<3>(M);
+        case 4: return rows_partials<4>(M);
+        case 5: return rows_partials<5>(M);
+        case 6: return rows_partials<6>(M);
+        case 7: return rows_partials<7>(M);
+        case 8: return rows_partials<8>(M);
+        case 9: return rows_partials<9>(M);
+        case 10: return rows_partials<10>(M);
+        case 11: return rows_partials<11>(M);
+        case 12: return rows_partials<12>(M);
+        case 13: return rows_partials<13>(M);
+        default: return 0;
+    }
 }
 
 hipError_t launch_rows(int logl, int mode, RowIn in, RowOut out, const RowArgs& a, const float2* tw, hipStream_t s) {
