@@ -101,7 +101,8 @@ def main():
     P = S * S
     seed = SEEDS.get(S, 0x5EED0000)
 
-    plan = fdr.Plan(S, S, mode, device=local_rank)
+    flags = fdr.FLAG_NO_PIPELINE if os.environ.get("FDR_NO_PIPELINE") == "1" else 0
+    plan = fdr.Plan(S, S, mode, device=local_rank, flags=flags)
     stream = torch.cuda.current_stream().cuda_stream
     plan.set_psf_motion(50, 30.0, 0.01, stream=stream)  # PSF generated, padded and transformed on the device
     imgs = torch.empty((B, S, S), dtype=torch.float32, device=dev)

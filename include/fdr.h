@@ -43,6 +43,9 @@ extern "C" {
 #define FDR_FLAG_SIMPLE_PATH 1u /* reference-shaped kernels: row FFT, transpose, row FFT, transpose
                                    (fft/fft_gpu.cu:214-240); slow, used as an on-device cross-check */
 
+#define FDR_FLAG_NO_PIPELINE 2u /* fast mode: one workgroup per column tile instead of the persistent,
+                                   register-double-buffered pass B' (A/B comparison and debugging)  */
+
 /* normalisation area selector for fdr_wiener_* */
 #define FDR_NORM_PADDED 1  /* serial semantics: min/max over the padded M x N area, then crop
                               (serial.cpp:36-38 + fft/fft_serial.cpp:243-246)                 */

@@ -15,11 +15,13 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfdr.so")
+# FDR_LIB_PATH selects an alternative build of the same library (timing-only debug builds)
+LIB_PATH = os.environ.get("FDR_LIB_PATH") or os.path.join(_HERE, "libfdr.so")
 
 MODE_PARITY = 0
 MODE_FAST = 1
 FLAG_SIMPLE_PATH = 1
+FLAG_NO_PIPELINE = 2
 NORM_PADDED = 1
 NORM_CROPPED = 0
 MAX_PASSES = 8

@@ -104,6 +104,8 @@ struct fdr_plan {
     int device = 0, M = 0, N = 0, logM = 0, logN = 0, mode = 0;
     unsigned flags = 0;
     bool simple = false;
+    int num_cu = 256;
+    int no_pipeline = 0;
     float2 *tw_row_f = nullptr, *tw_row_i = nullptr, *tw_col_f = nullptr, *tw_col_i = nullptr;
     float2* work = nullptr;   // M x N complex working spectrum
     float2* work2 = nullptr;  // simple path: N x M transpose buffer
@@ -164,7 +166,8 @@ int dft2d_dev(fdr_plan* p, float2* d, bool inverse, hipStream_t s) {
     }
     RowArgs ra{};
     ra.src_c = d; ra.dst_c = d; ra.M = p->M;
-    FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, ra, twr, s));
+    FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, inverse, ra,
+                        p->mode == FDR_MODE_FAST ? p->tw_row_f : twr, s));
     ColArgs ca{};
     ca.data = d; ca.N = p->N;
     FDR_HIP(launch_cols(p->logM, p->mode, inverse ? COL_INV : COL_FWD, ca, p->tw_col_f, p->tw_col_i, s));
@@ -184,7 +187,7 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
         RowArgs ra{};
         ra.src_real = d_psf; ra.src_rows = prows; ra.src_cols = pcols; ra.src_stride = pstride;
         ra.dst_c = p->filt; ra.M = p->M;
-        FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_REAL, ROW_OUT_COMPLEX, ra, p->tw_row_f, s));
+        FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_REAL, ROW_OUT_COMPLEX, false, ra, p->tw_row_f, s));
         ColArgs ca{};
         ca.data = p->filt; ca.N = p->N;
         FDR_HIP(launch_cols(p->logM, p->mode, COL_FWD, ca, p->tw_col_f, p->tw_col_i, s));
@@ -222,7 +225,7 @@ int wiener_dev_impl(fdr_plan* p, const float* d_img, int rows, int cols, int str
             RowArgs a{};
             a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
             a.dst_c = p->work; a.M = p->M;
-            FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
+            FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_REAL, ROW_OUT_COMPLEX, false, a, p->tw_row_f, s));
         }
         {   // B: columns forward + Wiener quotient (:176 second half, :186-224)
             ScopedPass t(p, s, kPassColsWiener);
@@ -234,7 +237,7 @@ int wiener_dev_impl(fdr_plan* p, const float* d_img, int rows, int cols, int str
             ScopedPass t(p, s, kPassRowsInv);
             RowArgs a{};
             a.src_c = p->work; a.dst_c = p->work; a.M = p->M;
-            FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, a, p->tw_row_i, s));
+            FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, true, a, p->tw_row_i, s));
         }
         {   // D: columns inverse, real plane, min/max (:229 second half, :236-240, minMaxIdx of :246)
             ScopedPass t(p, s, kPassColsInvReal);
@@ -249,19 +252,19 @@ int wiener_dev_impl(fdr_plan* p, const float* d_img, int rows, int cols, int str
             RowArgs a{};
             a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
             a.dst_c = p->work; a.M = p->M;
-            FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
+            FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_REAL, ROW_OUT_COMPLEX, false, a, p->tw_row_f, s));
         }
         {   // B': columns forward, multiply by W, columns inverse -- one HBM round trip
             ScopedPass t(p, s, kPassColsFused);
             ColArgs c{};
-            c.data = p->work; c.filt = p->filt; c.K = p->K; c.N = p->N;
+            c.data = p->work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu; c.no_pipeline = p->no_pipeline;
             FDR_HIP(launch_cols(p->logM, p->mode, COL_FUSED, c, p->tw_col_f, p->tw_col_i, s));
         }
         {   // C': rows inverse, real plane, min/max
             ScopedPass t(p, s, kPassRowsInvReal);
             RowArgs a{};
             a.src_c = p->work; a.dst_real = p->raw; a.mm_part = p->mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
-            FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, a, p->tw_row_i, s));
+            FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, true, a, p->tw_row_f, s));
             n_part = rows_minmax_partials(p->logN, p->M);
         }
     }
@@ -311,6 +314,11 @@ int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan
     if (!p) return fail(FDR_ERR_ALLOC, "fdr_plan_create: out of host memory");
     p->device = device; p->M = M; p->N = N; p->logM = ilog2(M); p->logN = ilog2(N); p->mode = mode; p->flags = flags;
     p->simple = (flags & FDR_FLAG_SIMPLE_PATH) != 0 || M < 8 || N < 8;
+    p->no_pipeline = (flags & FDR_FLAG_NO_PIPELINE) != 0;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) p->num_cu = cus;
+    }
     const size_t P = (size_t)M * N;
     std::vector<float2> t;
     int rc = FDR_OK;
@@ -484,7 +492,9 @@ int fdr_fft1d_c2c(float* data_host, int n, int inverse, int mode) {
     if (!fdr_is_pow2(n)) return fdr_dft_naive_c2c(data_host, n, inverse);  // fft/fft_serial.cpp:100-101
     if (n > 8192) return fail(FDR_ERR_ARG, "fdr_fft1d_c2c: power-of-two length above 8192 (one row must fit LDS)");
     std::vector<float2> t;
-    build_twiddles(n, mode, inverse != 0, t);
+    // the register kernels take the forward table in fast mode (they conjugate it); the simple kernel
+    // (n < 8) and parity mode take the table of the requested direction
+    build_twiddles(n, mode, (mode == FDR_MODE_FAST && n >= 8) ? false : (inverse != 0), t);
     float2 *tw = nullptr, *d = nullptr;
     const size_t bytes = (size_t)n * sizeof(float2);
     FDR_HIP(hipMalloc((void**)&tw, t.size() * sizeof(float2)));
@@ -496,7 +506,7 @@ int fdr_fft1d_c2c(float* data_host, int n, int inverse, int mode) {
         if (n >= 8) {
             RowArgs ra{};
             ra.src_c = d; ra.dst_c = d; ra.M = 1;
-            e = launch_rows(logn, mode, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, ra, tw, nullptr);
+            e = launch_rows(logn, mode, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, inverse != 0, ra, tw, nullptr);
         } else {
             e = launch_simple_rows(d, 1, n, logn, tw, mode, nullptr);
         }

@@ -31,7 +31,7 @@ hipError_t launch_pad_real_to_complex(const float* src, int rows, int cols, int 
 // table so that parity mode reproduces fft/fft_serial.cpp:53-66 bit for bit.
 template <class Pol>
 __global__ void simple_rows_kernel(float2* __restrict__ data, int rows, int L, int logl, const float2* __restrict__ tw) {
-    extern __shared__ float2 s_data[];
+    extern __shared__ float2 s_data[];  // tw: table of the requested direction (both modes)
     const int row = blockIdx.x;
     if (row >= rows) return;
     float2* p = data + (size_t)row * L;

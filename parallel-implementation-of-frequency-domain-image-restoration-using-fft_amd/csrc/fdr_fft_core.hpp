@@ -49,9 +49,21 @@ struct Steps {
 // ---------------------------------------------------------------------------------------------
 // arithmetic policies.  This translation unit is compiled with -ffp-contract=off, so a*b+c below
 // is two roundings unless __builtin_fmaf is written explicitly.
+//
+// A radix-2^LR step needs the twiddles of LR consecutive stages (LP = sub-transform size before
+// the step, k = frequency index of the butterfly, k < LP):
+//   w1 = T_{2LP}[k];  w2a = T_{4LP}[k], w2b = T_{4LP}[k+LP];  w3a..d = T_{8LP}[k + LP c], c = 0..3
+// with T_len stored at table offset len/2 - 1.
 // ---------------------------------------------------------------------------------------------
+struct TwSet {
+    float2 w1, w2a, w2b, w3a, w3b, w3c, w3d;
+};
+
+// Parity: every twiddle comes from the table (values replayed from the serial recurrence, so not
+// even T_4[1] = (-4.37e-8, -1) is replaced by -i); every product and sum is rounded separately.
+// The table passed in is already direction specific, INV is ignored.
 struct PolicyParity {
-    static constexpr bool kFma = false;
+    static constexpr bool kHoist = false;
     static __device__ __forceinline__ void bfly(float2& u, float2& v, const float2 w) {
         const float tr = v.x * w.x - v.y * w.y;
         const float ti = v.x * w.y + v.y * w.x;
@@ -59,9 +71,28 @@ struct PolicyParity {
         u.x = ur + tr; u.y = ui + ti;
         v.x = ur - tr; v.y = ui - ti;
     }
+    template <int LR, int LP>
+    static __device__ __forceinline__ float2 base(const float2* __restrict__, int) { return make_float2(1.f, 0.f); }
+    template <int LR, int LP, bool INV>
+    static __device__ __forceinline__ TwSet twiddles(const float2* __restrict__ tw, int k, float2) {
+        TwSet t;
+        t.w1 = tw[(LP - 1) + k];
+        if constexpr (LR >= 2) { t.w2a = tw[(2 * LP - 1) + k]; t.w2b = tw[(2 * LP - 1) + k + LP]; }
+        if constexpr (LR >= 3) {
+            t.w3a = tw[(4 * LP - 1) + k]; t.w3b = tw[(4 * LP - 1) + k + LP];
+            t.w3c = tw[(4 * LP - 1) + k + 2 * LP]; t.w3d = tw[(4 * LP - 1) + k + 3 * LP];
+        }
+        return t;
+    }
 };
+
+// Fast: FMA butterflies (6 FMAs), and ONE table value per step -- the twiddle of the step's last
+// stage, w = exp(-+2 pi i k / (2^LR LP)) from the double-generated forward table -- from which the
+// others follow: w^2, w^4 and rotations by multiples of pi/4.  A thread's k never changes, so the
+// base values are fetched once per kernel (kHoist) and no vector-memory load sits inside the
+// transform: prefetches of the next tile stay in flight behind it (vmcnt is an in-order counter).
 struct PolicyFast {
-    static constexpr bool kFma = true;
+    static constexpr bool kHoist = true;
     static __device__ __forceinline__ void bfly(float2& u, float2& v, const float2 w) {
         // u' = u + v*w in 4 FMAs, v' = 2u - u' in 2 FMAs
         const float ar = __builtin_fmaf(v.x, w.x, __builtin_fmaf(-v.y, w.y, u.x));
@@ -70,41 +101,67 @@ struct PolicyFast {
         v.y = __builtin_fmaf(2.0f, u.y, -ai);
         u.x = ar; u.y = ai;
     }
+    static __device__ __forceinline__ float2 csq(float2 a) {
+        return make_float2(__builtin_fmaf(a.x, a.x, -(a.y * a.y)), 2.0f * a.x * a.y);
+    }
+    template <int LR, int LP>
+    static __device__ __forceinline__ float2 base(const float2* __restrict__ tw_fwd, int k) {
+        return tw_fwd[((LP << (LR - 1)) - 1) + k];  // T_{2^LR LP}[k], forward direction
+    }
+    template <int LR, int LP, bool INV>
+    static __device__ __forceinline__ TwSet twiddles(const float2* __restrict__, int, float2 b) {
+        // Opaque to the optimiser on purpose: in the persistent kernels the derived set is loop
+        // invariant, and LICM would hoist all S x 2 sets (100+ VGPRs) out of the tile loop and
+        // spill them -- scratch reloads are vector-memory loads and would drain the prefetch queue.
+        asm volatile("" : "+v"(b.x), "+v"(b.y));
+        const float2 w = INV ? make_float2(b.x, -b.y) : b;
+        TwSet t;
+        // multiplying by -i (forward) / +i (inverse): (x, y) -> (y, -x) / (-y, x)
+        auto rot = [](float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); };
+        if constexpr (LR == 1) {
+            t.w1 = w;
+        } else if constexpr (LR == 2) {
+            t.w2a = w; t.w2b = rot(w); t.w1 = csq(w);
+        } else {
+            const float c = 0.70710678118654752440f;
+            t.w3a = w; t.w3c = rot(w);
+            // w * exp(-+i pi/4) and w * exp(-+3i pi/4)
+            const float2 d = INV ? make_float2(c * (w.x - w.y), c * (w.x + w.y)) : make_float2(c * (w.x + w.y), c * (w.y - w.x));
+            t.w3b = d; t.w3d = rot(d);
+            t.w2a = csq(w); t.w2b = rot(t.w2a);
+            t.w1 = csq(t.w2a);
+        }
+        return t;
+    }
 };
 
 __device__ __forceinline__ void swap2(float2& a, float2& b) { const float2 t = a; a = b; b = t; }
 
 // One radix-2^LR step on RHO = 2^LR values x[0..RHO) holding Y_s[r + R q][k], q = 0..RHO-1, leaving
-// Y_{s+LR}[r][k + LP q'] in x[q'].  tw = per-stage table (stage len at offset len/2 - 1), LP = 2^s.
-template <int LR, int LP, class Pol>
-__device__ __forceinline__ void radix_step(float2* x, const float2* __restrict__ tw, const int k) {
+// Y_{s+LR}[r][k + LP q'] in x[q'].
+template <int LR, class Pol>
+__device__ __forceinline__ void radix_step(float2* x, const TwSet& t) {
     if constexpr (LR == 1) {
-        Pol::bfly(x[0], x[1], tw[(LP - 1) + k]);
+        Pol::bfly(x[0], x[1], t.w1);
     } else if constexpr (LR == 2) {
-        const float2 w1 = tw[(LP - 1) + k];
-        const float2 w2a = tw[(2 * LP - 1) + k], w2b = tw[(2 * LP - 1) + k + LP];
-        Pol::bfly(x[0], x[2], w1);
-        Pol::bfly(x[1], x[3], w1);
-        Pol::bfly(x[0], x[1], w2a);
-        Pol::bfly(x[2], x[3], w2b);
+        Pol::bfly(x[0], x[2], t.w1);
+        Pol::bfly(x[1], x[3], t.w1);
+        Pol::bfly(x[0], x[1], t.w2a);
+        Pol::bfly(x[2], x[3], t.w2b);
         swap2(x[1], x[2]);
     } else {
-        const float2 w1 = tw[(LP - 1) + k];
-        const float2 w2a = tw[(2 * LP - 1) + k], w2b = tw[(2 * LP - 1) + k + LP];
-        const float2 w3a = tw[(4 * LP - 1) + k], w3b = tw[(4 * LP - 1) + k + LP];
-        const float2 w3c = tw[(4 * LP - 1) + k + 2 * LP], w3d = tw[(4 * LP - 1) + k + 3 * LP];
-        Pol::bfly(x[0], x[4], w1);
-        Pol::bfly(x[1], x[5], w1);
-        Pol::bfly(x[2], x[6], w1);
-        Pol::bfly(x[3], x[7], w1);
-        Pol::bfly(x[0], x[2], w2a);
-        Pol::bfly(x[1], x[3], w2a);
-        Pol::bfly(x[4], x[6], w2b);
-        Pol::bfly(x[5], x[7], w2b);
-        Pol::bfly(x[0], x[1], w3a);
-        Pol::bfly(x[4], x[5], w3b);
-        Pol::bfly(x[2], x[3], w3c);
-        Pol::bfly(x[6], x[7], w3d);
+        Pol::bfly(x[0], x[4], t.w1);
+        Pol::bfly(x[1], x[5], t.w1);
+        Pol::bfly(x[2], x[6], t.w1);
+        Pol::bfly(x[3], x[7], t.w1);
+        Pol::bfly(x[0], x[2], t.w2a);
+        Pol::bfly(x[1], x[3], t.w2a);
+        Pol::bfly(x[4], x[6], t.w2b);
+        Pol::bfly(x[5], x[7], t.w2b);
+        Pol::bfly(x[0], x[1], t.w3a);
+        Pol::bfly(x[4], x[5], t.w3b);
+        Pol::bfly(x[2], x[3], t.w3c);
+        Pol::bfly(x[6], x[7], t.w3d);
         swap2(x[1], x[4]);
         swap2(x[3], x[6]);
     }
@@ -131,6 +188,20 @@ struct FftCore {
     static __device__ __forceinline__ int in_index(int tid, int u, int q) { return (tid + u * T) + (q << LOGR0); }
     static __device__ __forceinline__ int out_index(int tid, int u, int q) { return (tid + u * T) + (q << LOGOUT); }
 
+    // per-thread hoisted twiddle bases (fast policy): one value per step and butterfly slot
+    struct Bases { float2 b[S][4]; };
+
+    template <int J>
+    static __device__ __forceinline__ void init_bases_from(Bases& bs, const float2* __restrict__ tw, int tid) {
+        constexpr int LR = St::lr(J), NU = St::nu(J), LOGR = St::logR(J), LP = 1 << St::lprev(J);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) bs.b[J][u] = Pol::template base<LR, LP>(tw, (tid + u * T) >> LOGR);
+        if constexpr (J + 1 < S) init_bases_from<J + 1>(bs, tw, tid);
+    }
+    static __device__ __forceinline__ void init_bases(Bases& bs, const float2* __restrict__ tw, int tid) {
+        if constexpr (Pol::kHoist) init_bases_from<0>(bs, tw, tid);
+    }
+
     template <int J>
     static __device__ __forceinline__ int pad(int a) {
         // layout read by step J+1: runs of R' elements every RHO'*R'; skew each run by R'
@@ -139,14 +210,15 @@ struct FftCore {
         else return a;
     }
 
-    template <int J>
-    static __device__ __forceinline__ void butterflies(float2 (&v)[B][8], const float2* __restrict__ tw, int tid) {
+    template <int J, bool INV>
+    static __device__ __forceinline__ void butterflies(float2 (&v)[B][8], const float2* __restrict__ tw, const Bases& bs, int tid) {
         constexpr int LR = St::lr(J), NU = St::nu(J), RHO = 1 << LR, LOGR = St::logR(J), LP = 1 << St::lprev(J);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int k = (tid + u * T) >> LOGR;
+            const TwSet t = Pol::template twiddles<LR, LP, INV>(tw, k, bs.b[J][u]);
 #pragma unroll
-            for (int b = 0; b < B; ++b) radix_step<LR, LP, Pol>(&v[b][u * RHO], tw, k);
+            for (int b = 0; b < B; ++b) radix_step<LR, Pol>(&v[b][u * RHO], t);
         }
     }
 
@@ -174,18 +246,25 @@ struct FftCore {
         }
     }
 
-    template <int J, int SEQ0>
-    static __device__ __forceinline__ void steps_from(float2 (&v)[B][8], float2* lds, const float2* __restrict__ tw, int tid) {
-        butterflies<J>(v, tw, tid);
+    template <int J, int SEQ0, bool INV>
+    static __device__ __forceinline__ void steps_from(float2 (&v)[B][8], float2* lds, const float2* __restrict__ tw,
+                                                      const Bases& bs, int tid) {
+        butterflies<J, INV>(v, tw, bs, tid);
         if constexpr (J + 1 < S) {
             exchange<J, SEQ0>(v, lds, tid);
-            steps_from<J + 1, SEQ0>(v, lds, tw, tid);
+            steps_from<J + 1, SEQ0, INV>(v, lds, tw, bs, tid);
         }
     }
 
-    template <int SEQ0 = 0>
-    static __device__ __forceinline__ void run(float2 (&v)[B][8], float2* lds, const float2* __restrict__ tw, int tid) {
-        steps_from<0, SEQ0>(v, lds, tw, tid);
+    // tw: parity -> the direction-specific recurrence table; fast -> unused once bases are hoisted
+    template <int SEQ0, bool INV>
+    static __device__ __forceinline__ void run(float2 (&v)[B][8], float2* lds, const float2* __restrict__ tw, const Bases& bs,
+                                               int tid) {
+#ifdef FDR_DEBUG_SKIP_FFT  // timing-only builds (tools/microbench): memory phases without the transform
+        (void)lds; (void)tw; (void)bs; (void)tid; (void)v;
+#else
+        steps_from<0, SEQ0, INV>(v, lds, tw, bs, tid);
+#endif
     }
 };
 

@@ -38,10 +38,14 @@ struct ColArgs {
     float2* mm_part;  // one (min, max) partial per workgroup
     int mm_rows, mm_cols;
     int N;  // row length (number of columns)
+    int num_cu;       // CUs of the device (persistent pass B' launches one workgroup per CU)
+    int no_pipeline;  // debug/bench: use the non-persistent fused kernel
 };
 
 // launchers (fdr_rows.hip / fdr_cols.hip); logl = log2 of the transform length, 3..13
-hipError_t launch_rows(int logl, int mode, RowIn in, RowOut out, const RowArgs& a, const float2* tw, hipStream_t s);
+// tw: parity mode -> table of the requested direction; fast mode -> the forward table (inverse = conjugate)
+hipError_t launch_rows(int logl, int mode, RowIn in, RowOut out, bool inverse, const RowArgs& a, const float2* tw,
+                       hipStream_t s);
 hipError_t launch_cols(int logm, int mode, ColKind kind, const ColArgs& a, const float2* tw_fwd, const float2* tw_inv,
                        hipStream_t s);
 

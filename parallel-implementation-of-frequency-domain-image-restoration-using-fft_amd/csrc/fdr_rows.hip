@@ -18,7 +18,9 @@ struct RowGeom {
     static constexpr int THREADS = T * G;
 };
 
-template <int LOGL, class Pol, int IN, int OUT>
+// INV matters only to the fast policy (it conjugates the hoisted forward twiddles); the parity
+// policy receives a direction-specific table and is instantiated with INV = false only.
+template <int LOGL, class Pol, int IN, int OUT, bool INV>
 __global__ __launch_bounds__(RowGeom<LOGL>::THREADS) void fft_rows_kernel(const RowArgs a, const float2* __restrict__ tw) {
     using St = Steps<LOGL>;
     using Core = FftCore<LOGL, 1, 1, Pol>;
@@ -28,6 +30,9 @@ __global__ __launch_bounds__(RowGeom<LOGL>::THREADS) void fft_rows_kernel(const 
     const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
     const int row = blockIdx.x * G + g;
     const bool active = row < a.M;
+
+    typename Core::Bases bases;
+    Core::init_bases(bases, tw, tid);
 
     float2 v[1][8];
 #pragma unroll
@@ -44,7 +49,7 @@ __global__ __launch_bounds__(RowGeom<LOGL>::THREADS) void fft_rows_kernel(const 
             v[0][u * Core::RHO0 + q] = x;
         }
 
-    Core::run(v, lds + g * St::BUF, tw, tid);
+    Core::template run<0, INV>(v, lds + g * St::BUF, tw, bases, tid);
 
     if (OUT == ROW_OUT_COMPLEX) {
         if (active) {
@@ -74,25 +79,33 @@ __global__ __launch_bounds__(RowGeom<LOGL>::THREADS) void fft_rows_kernel(const 
     }
 }
 
-template <int LOGL, class Pol>
+template <int LOGL, class Pol, bool INV>
 static hipError_t launch_rows_io(RowIn in, RowOut out, const RowArgs& a, const float2* tw, hipStream_t s) {
     constexpr int G = RowGeom<LOGL>::G, THREADS = RowGeom<LOGL>::THREADS;
     const dim3 grid((a.M + G - 1) / G), block(THREADS);
     if (in == ROW_IN_REAL && out == ROW_OUT_COMPLEX)
-        hipLaunchKernelGGL((fft_rows_kernel<LOGL, Pol, ROW_IN_REAL, ROW_OUT_COMPLEX>), grid, block, 0, s, a, tw);
+        hipLaunchKernelGGL((fft_rows_kernel<LOGL, Pol, ROW_IN_REAL, ROW_OUT_COMPLEX, INV>), grid, block, 0, s, a, tw);
     else if (in == ROW_IN_COMPLEX && out == ROW_OUT_COMPLEX)
-        hipLaunchKernelGGL((fft_rows_kernel<LOGL, Pol, ROW_IN_COMPLEX, ROW_OUT_COMPLEX>), grid, block, 0, s, a, tw);
+        hipLaunchKernelGGL((fft_rows_kernel<LOGL, Pol, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, INV>), grid, block, 0, s, a, tw);
     else if (in == ROW_IN_COMPLEX && out == ROW_OUT_REAL_MINMAX)
-        hipLaunchKernelGGL((fft_rows_kernel<LOGL, Pol, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX>), grid, block, 0, s, a, tw);
+        hipLaunchKernelGGL((fft_rows_kernel<LOGL, Pol, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, INV>), grid, block, 0, s, a, tw);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
+// tw: parity -> the table of the requested direction; fast -> always the forward table
 template <int LOGL>
-static hipError_t launch_rows_mode(int mode, RowIn in, RowOut out, const RowArgs& a, const float2* tw, hipStream_t s) {
-    return mode == 0 ? launch_rows_io<LOGL, PolicyParity>(in, out, a, tw, s)
-                     : launch_rows_io<LOGL, PolicyFast>(in, out, a, tw, s);
+static hipError_t launch_rows_mode(int mode, RowIn in, RowOut out, bool inverse, const RowArgs& a, const float2* tw,
+                                   hipStream_t s) {
+    if (mode == 0) return launch_rows_io<LOGL, PolicyParity, false>(in, out, a, tw, s);
+    // fast mode: real input is only ever transformed forward, real output only ever inverse
+    if (inverse) {
+        if (in == ROW_IN_REAL) return hipErrorInvalidValue;
+        return launch_rows_io<LOGL, PolicyFast, true>(in, out, a, tw, s);
+    }
+    if (out == ROW_OUT_REAL_MINMAX) return hipErrorInvalidValue;
+    return launch_rows_io<LOGL, PolicyFast, false>(in, out, a, tw, s);
 }
 
 template <int LOGL>
@@ -115,19 +128,20 @@ int rows_minmax_partials(int logl, int M) {
     }
 }
 
-hipError_t launch_rows(int logl, int mode, RowIn in, RowOut out, const RowArgs& a, const float2* tw, hipStream_t s) {
+hipError_t launch_rows(int logl, int mode, RowIn in, RowOut out, bool inverse, const RowArgs& a, const float2* tw,
+                       hipStream_t s) {
     switch (logl) {
-        case 3: return launch_rows_mode<3>(mode, in, out, a, tw, s);
-        case 4: return launch_rows_mode<4>(mode, in, out, a, tw, s);
-        case 5: return launch_rows_mode<5>(mode, in, out, a, tw, s);
-        case 6: return launch_rows_mode<6>(mode, in, out, a, tw, s);
-        case 7: return launch_rows_mode<7>(mode, in, out, a, tw, s);
-        case 8: return launch_rows_mode<8>(mode, in, out, a, tw, s);
-        case 9: return launch_rows_mode<9>(mode, in, out, a, tw, s);
-        case 10: return launch_rows_mode<10>(mode, in, out, a, tw, s);
-        case 11: return launch_rows_mode<11>(mode, in, out, a, tw, s);
-        case 12: return launch_rows_mode<12>(mode, in, out, a, tw, s);
-        case 13: return launch_rows_mode<13>(mode, in, out, a, tw, s);
+        case 3: return launch_rows_mode<3>(mode, in, out, inverse, a, tw, s);
+        case 4: return launch_rows_mode<4>(mode, in, out, inverse, a, tw, s);
+        case 5: return launch_rows_mode<5>(mode, in, out, inverse, a, tw, s);
+        case 6: return launch_rows_mode<6>(mode, in, out, inverse, a, tw, s);
+        case 7: return launch_rows_mode<7>(mode, in, out, inverse, a, tw, s);
+        case 8: return launch_rows_mode<8>(mode, in, out, inverse, a, tw, s);
+        case 9: return launch_rows_mode<9>(mode, in, out, inverse, a, tw, s);
+        case 10: return launch_rows_mode<10>(mode, in, out, inverse, a, tw, s);
+        case 11: return launch_rows_mode<11>(mode, in, out, inverse, a, tw, s);
+        case 12: return launch_rows_mode<12>(mode, in, out, inverse, a, tw, s);
+        case 13: return launch_rows_mode<13>(mode, in, out, inverse, a, tw, s);
         default: return hipErrorInvalidValue;
     }
 }
