@@ -46,6 +46,9 @@ extern "C" {
 #define FDR_FLAG_NO_PIPELINE 2u /* fast mode: one workgroup per column tile instead of the persistent,
                                    register-double-buffered pass B' (A/B comparison and debugging)  */
 
+#define FDR_FLAG_ROWMAJOR 4u    /* fast mode: keep the intermediate spectrum row-major (32-byte column
+                                   tiles) instead of panel-major; slower, kept for A/B measurements   */
+
 /* normalisation area selector for fdr_wiener_* */
 #define FDR_NORM_PADDED 1  /* serial semantics: min/max over the padded M x N area, then crop
                               (serial.cpp:36-38 + fft/fft_serial.cpp:243-246)                 */

@@ -106,6 +106,7 @@ struct fdr_plan {
     bool simple = false;
     int num_cu = 256;
     int no_pipeline = 0;
+    bool panel = false;  // fast mode: panel-major intermediate spectrum and filter
     float2 *tw_row_f = nullptr, *tw_row_i = nullptr, *tw_col_f = nullptr, *tw_col_i = nullptr;
     float2* work = nullptr;   // M x N complex working spectrum
     float2* work2 = nullptr;  // simple path: N x M transpose buffer
@@ -183,6 +184,14 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
         FDR_HIP(launch_pad_real_to_complex(d_psf, prows, pcols, pstride, p->filt, p->M, p->N, s));
         int rc = dft2d_dev(p, p->filt, false, s);
         if (rc != FDR_OK) return rc;
+    } else if (p->panel) {
+        RowArgs ra{};
+        ra.src_real = d_psf; ra.src_rows = prows; ra.src_cols = pcols; ra.src_stride = pstride;
+        ra.dst_c = p->filt; ra.M = p->M;
+        FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, ra, p->tw_row_f, s));
+        ColArgs ca{};
+        ca.data = p->filt; ca.N = p->N; ca.num_cu = p->num_cu;
+        FDR_HIP(launch_cols_panel(p->logM, COL_FWD, ca, p->tw_col_f, s));
     } else {
         RowArgs ra{};
         ra.src_real = d_psf; ra.src_rows = prows; ra.src_cols = pcols; ra.src_stride = pstride;
@@ -245,6 +254,27 @@ int wiener_dev_impl(fdr_plan* p, const float* d_img, int rows, int cols, int str
             c.data = p->work; c.dst_real = p->raw; c.mm_part = p->mm_part; c.mm_rows = mm_rows; c.mm_cols = mm_cols; c.N = p->N;
             FDR_HIP(launch_cols(p->logM, p->mode, COL_INV_REAL, c, p->tw_col_f, p->tw_col_i, s));
             n_part = cols_minmax_partials(p->logM, p->N);
+        }
+    } else if (p->panel) {
+        {   // A: 4 rows per thread group, real -> panel-major spectrum
+            ScopedPass t(p, s, kPassRowsFwd);
+            RowArgs a{};
+            a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
+            a.dst_c = p->work; a.M = p->M;
+            FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
+        }
+        {   // B': per panel, columns forward * W * inverse, persistent + register double-buffered
+            ScopedPass t(p, s, kPassColsFused);
+            ColArgs c{};
+            c.data = p->work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu; c.no_pipeline = p->no_pipeline;
+            FDR_HIP(launch_cols_panel(p->logM, COL_FUSED, c, p->tw_col_f, s));
+        }
+        {   // C': 4 rows gathered from the panels, inverse, real plane, min/max
+            ScopedPass t(p, s, kPassRowsInvReal);
+            RowArgs a{};
+            a.src_c = p->work; a.dst_real = p->raw; a.mm_part = p->mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
+            FDR_HIP(launch_rows4(p->logN, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, a, p->tw_row_f, s));
+            n_part = rows4_minmax_partials(p->logN, p->M);
         }
     } else {
         {   // A
@@ -315,6 +345,7 @@ int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan
     p->device = device; p->M = M; p->N = N; p->logM = ilog2(M); p->logN = ilog2(N); p->mode = mode; p->flags = flags;
     p->simple = (flags & FDR_FLAG_SIMPLE_PATH) != 0 || M < 8 || N < 8;
     p->no_pipeline = (flags & FDR_FLAG_NO_PIPELINE) != 0;
+    p->panel = mode == FDR_MODE_FAST && !p->simple && (flags & FDR_FLAG_ROWMAJOR) == 0;
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) p->num_cu = cus;

@@ -34,17 +34,6 @@ __device__ __forceinline__ int col_tile_of_block(int b, int ntiles, int share) {
 // wave-uniform 64-bit base (row block q, kept in SGPRs) and ONE unsigned 32-bit per-thread element
 // offset ((tid + T u) * N + col0), so the 16 wide loads of a tile share a single address VGPR
 // (global_load_dwordx4 v, v_off, s[base]) instead of 16 64-bit pointers.  M*N*8 < 4 GiB here.
-__device__ __forceinline__ void load4(const float2* p, float2& a, float2& b, float2& c, float2& d) {
-    const float4 lo = *reinterpret_cast<const float4*>(p);
-    const float4 hi = *reinterpret_cast<const float4*>(p + 2);
-    a = make_float2(lo.x, lo.y); b = make_float2(lo.z, lo.w);
-    c = make_float2(hi.x, hi.y); d = make_float2(hi.z, hi.w);
-}
-__device__ __forceinline__ void store4(float2* p, float2 a, float2 b, float2 c, float2 d) {
-    *reinterpret_cast<float4*>(p) = make_float4(a.x, a.y, b.x, b.y);
-    *reinterpret_cast<float4*>(p + 2) = make_float4(c.x, c.y, d.x, d.y);
-}
-
 // fft/fft_serial.cpp:186-224 in the reference's operation order, every op rounded separately:
 // mag = sqrt(Hr^2 + Hi^2); denom = mag*mag + K; num = G * conj(H); out = num / denom.
 __device__ __forceinline__ float2 wiener_parity(float2 g, float2 h, float K) {
@@ -60,10 +49,6 @@ __device__ __forceinline__ float2 wiener_parity(float2 g, float2 h, float K) {
     o.y = denom != 0.0f ? ni / denom : 0.0f;
     return o;
 }
-__device__ __forceinline__ float2 cmul_fma(float2 a, float2 w) {
-    return make_float2(__builtin_fmaf(a.x, w.x, -(a.y * w.y)), __builtin_fmaf(a.x, w.y, a.y * w.x));
-}
-
 template <int LOGM, class Pol, int KIND>
 __global__ __launch_bounds__(ColGeom<LOGM>::THREADS, ColGeom<LOGM>::WAVES_PER_SIMD) void fft_cols_kernel(const ColArgs a, const float2* __restrict__ tw_fwd,
                                                                           const float2* __restrict__ tw_inv) {

@@ -135,6 +135,21 @@ struct PolicyFast {
     }
 };
 
+__device__ __forceinline__ void load4(const float2* p, float2& a, float2& b, float2& c, float2& d) {
+    const float4 lo = *reinterpret_cast<const float4*>(p);
+    const float4 hi = *reinterpret_cast<const float4*>(p + 2);
+    a = make_float2(lo.x, lo.y); b = make_float2(lo.z, lo.w);
+    c = make_float2(hi.x, hi.y); d = make_float2(hi.z, hi.w);
+}
+__device__ __forceinline__ void store4(float2* p, float2 a, float2 b, float2 c, float2 d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a.x, a.y, b.x, b.y);
+    *reinterpret_cast<float4*>(p + 2) = make_float4(c.x, c.y, d.x, d.y);
+}
+
+__device__ __forceinline__ float2 cmul_fma(float2 a, float2 w) {
+    return make_float2(__builtin_fmaf(a.x, w.x, -(a.y * w.y)), __builtin_fmaf(a.x, w.y, a.y * w.x));
+}
+
 __device__ __forceinline__ void swap2(float2& a, float2& b) { const float2 t = a; a = b; b = t; }
 
 // One radix-2^LR step on RHO = 2^LR values x[0..RHO) holding Y_s[r + R q][k], q = 0..RHO-1, leaving

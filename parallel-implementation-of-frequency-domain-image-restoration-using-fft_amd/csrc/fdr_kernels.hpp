@@ -49,6 +49,13 @@ hipError_t launch_rows(int logl, int mode, RowIn in, RowOut out, bool inverse, c
 hipError_t launch_cols(int logm, int mode, ColKind kind, const ColArgs& a, const float2* tw_fwd, const float2* tw_inv,
                        hipStream_t s);
 
+// fast-mode passes on the panel-major intermediate (fdr_panel.hip); tw_fwd = forward table
+// rows4: (ROW_IN_REAL -> ROW_OUT_COMPLEX[panel]) forward, (ROW_IN_COMPLEX[panel] -> ROW_OUT_REAL_MINMAX) inverse
+hipError_t launch_rows4(int logl, RowIn in, RowOut out, const RowArgs& a, const float2* tw_fwd, hipStream_t s);
+int rows4_minmax_partials(int logl, int M);
+// cols_panel: COL_FWD (in place) or COL_FUSED (FFT . W . IFFT, persistent + register double-buffered)
+hipError_t launch_cols_panel(int logm, ColKind kind, const ColArgs& a, const float2* tw_fwd, hipStream_t s);
+
 // reference-shaped and auxiliary kernels (fdr_aux.hip)
 hipError_t launch_pad_real_to_complex(const float* src, int rows, int cols, int stride, float2* dst, int M, int N,
                                       hipStream_t s);

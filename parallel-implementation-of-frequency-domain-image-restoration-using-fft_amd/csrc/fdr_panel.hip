@@ -1,0 +1,347 @@
+// fdr_panel.hip -- fast-mode passes on a PANEL-MAJOR intermediate spectrum.
+//
+// Why: a column pass that keeps 4 adjacent columns of a row-major M x N array touches 32 of the
+// 128 bytes of every line; four workgroups share each line, and with >= 128 KB of lines in flight
+// per CU the sharing cannot be served from the 4 MiB XCD L2 -- measured on MI355X: pass B' with
+// the transform compiled out still took 191 us at 4096^2 (2.1 TB/s algorithmic, each line moved
+// ~4x).  The fix is a layout in which every pass moves whole lines:
+//
+//     panel_index(m, n) = ((n >> 2) * M + m) * 4 + (n & 3)        (M rows, N columns, float2)
+//
+// i.e. panels of 4 columns, each panel a contiguous M x 4 array.  A column tile (4 columns, all
+// rows) is then ONE contiguous 32*M-byte chunk, and a row workgroup that owns 4 consecutive rows
+// writes / reads complete 128-byte lines (4 rows x 4 columns) in every panel.
+//
+//   pass A  : 4 real rows  (zero-padded on load) -> row FFTs -> panel layout
+//   pass B' : one panel: column FFTs . W . column IFFTs, in place, persistent + register
+//             double-buffered (next panel's spectrum / filter stream in behind the butterflies)
+//   pass C' : 4 rows gathered from the panels -> row IFFTs -> real plane + min/max partial
+// The layout is private to a plan (never visible through the C ABI); W is stored the same way.
+#include "fdr_fft_core.hpp"
+#include "fdr_kernels.hpp"
+
+namespace fdr {
+
+// ---------------------------------------------------------------------------------------------
+// rows, 4 at a time
+// ---------------------------------------------------------------------------------------------
+template <int LOGL>
+struct Rows4Geom {
+    static constexpr int T = Steps<LOGL>::T;
+    static constexpr int G = T >= 256 ? 1 : 256 / T;  // 4-row groups per workgroup
+    static constexpr int THREADS = T * G;
+    // 512 threads = 2 waves/SIMD per workgroup; two workgroups per CU need <= 128 VGPRs
+    static constexpr int WAVES_PER_SIMD = THREADS >= 512 ? 4 : 1;
+};
+
+template <int LOGL, int IN, int OUT, bool INV>
+__global__ __launch_bounds__(Rows4Geom<LOGL>::THREADS, Rows4Geom<LOGL>::WAVES_PER_SIMD) void fft_rows4_kernel(
+    const RowArgs a, const float2* __restrict__ tw_fwd) {
+    using St = Steps<LOGL>;
+    using Geo = Rows4Geom<LOGL>;
+    constexpr int B = 4, G = Geo::G, T = St::T, L = St::L;
+    using Core = FftCore<LOGL, B, 2, PolicyFast>;
+    __shared__ float2 lds[G * 2 * St::BUF];
+
+    const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
+    const int M = a.M;
+    const int r0 = (blockIdx.x * G + g) * 4;
+    const bool active = r0 < M;  // M is a multiple of 4 on this path
+    const int rr = active ? r0 : 0;  // inactive groups read rows 0..3 (valid memory), store nothing
+
+    typename Core::Bases bases;
+    Core::init_bases(bases, tw_fwd, tid);
+
+    float2 v[B][8];
+#pragma unroll
+    for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+        for (int q = 0; q < Core::RHO0; ++q) {
+            const int s = u * Core::RHO0 + q;
+            const int n = Core::in_index(tid, u, q);
+            if (IN == ROW_IN_REAL) {
+#pragma unroll
+                for (int b = 0; b < B; ++b) {
+                    float x = 0.f;
+                    if (rr + b < a.src_rows && n < a.src_cols) x = a.src_real[(size_t)(rr + b) * a.src_stride + n];
+                    v[b][s] = make_float2(x, 0.f);
+                }
+            } else {
+                const float2* p = a.src_c + ((size_t)(n >> 2) * M + rr) * 4 + (n & 3);
+#pragma unroll
+                for (int b = 0; b < B; ++b) v[b][s] = p[b * 4];
+            }
+        }
+
+    Core::template run<0, INV>(v, lds + g * 2 * St::BUF, tw_fwd, bases, tid);
+
+    if (OUT == ROW_OUT_COMPLEX) {  // panel-major spectrum
+        if (active) {
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int s = u * Core::RHOL + q;
+                    const int n = Core::out_index(tid, u, q);
+                    float2* p = a.dst_c + ((size_t)(n >> 2) * M + r0) * 4 + (n & 3);
+#pragma unroll
+                    for (int b = 0; b < B; ++b) p[b * 4] = v[b][s];
+                }
+        }
+    } else {
+        float mn = __builtin_inff(), mx = -__builtin_inff();
+        if (active) {
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int s = u * Core::RHOL + q;
+                    const int n = Core::out_index(tid, u, q);
+#pragma unroll
+                    for (int b = 0; b < B; ++b) {
+                        const float r = v[b][s].x;
+                        a.dst_real[(size_t)(r0 + b) * L + n] = r;
+                        if (r0 + b < a.mm_rows && n < a.mm_cols) {
+                            mn = fminf(mn, r);
+                            mx = fmaxf(mx, r);
+                        }
+                    }
+                }
+        }
+        block_minmax_store(mn, mx, a.mm_part);
+    }
+}
+
+template <int LOGL>
+static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const float2* tw, hipStream_t s) {
+    using Geo = Rows4Geom<LOGL>;
+    const int groups = (a.M + 3) / 4;
+    const dim3 grid((groups + Geo::G - 1) / Geo::G), block(Geo::THREADS);
+    if (in == ROW_IN_REAL && out == ROW_OUT_COMPLEX)
+        hipLaunchKernelGGL((fft_rows4_kernel<LOGL, ROW_IN_REAL, ROW_OUT_COMPLEX, false>), grid, block, 0, s, a, tw);
+    else if (in == ROW_IN_COMPLEX && out == ROW_OUT_REAL_MINMAX)
+        hipLaunchKernelGGL((fft_rows4_kernel<LOGL, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, true>), grid, block, 0, s, a, tw);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+template <int LOGL>
+static int rows4_partials_t(int M) { return ((M + 3) / 4 + Rows4Geom<LOGL>::G - 1) / Rows4Geom<LOGL>::G; }
+
+#define FDR_DISPATCH_LOG(var, expr)                                                     \
+    switch (var) {                                                                      \
+        case 3: { constexpr int LG = 3; return expr; }                                  \
+        case 4: { constexpr int LG = 4; return expr; }                                  \
+        case 5: { constexpr int LG = 5; return expr; }                                  \
+        case 6: { constexpr int LG = 6; return expr; }                                  \
+        case 7: { constexpr int LG = 7; return expr; }                                  \
+        case 8: { constexpr int LG = 8; return expr; }                                  \
+        case 9: { constexpr int LG = 9; return expr; }                                  \
+        case 10: { constexpr int LG = 10; return expr; }                                \
+        case 11: { constexpr int LG = 11; return expr; }                                \
+        case 12: { constexpr int LG = 12; return expr; }                                \
+        case 13: { constexpr int LG = 13; return expr; }                                \
+        default: break;                                                                 \
+    }
+
+hipError_t launch_rows4(int logl, RowIn in, RowOut out, const RowArgs& a, const float2* tw_fwd, hipStream_t s) {
+    FDR_DISPATCH_LOG(logl, launch_rows4_t<LG>(in, out, a, tw_fwd, s));
+    return hipErrorInvalidValue;
+}
+
+int rows4_minmax_partials(int logl, int M) {
+    FDR_DISPATCH_LOG(logl, rows4_partials_t<LG>(M));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// columns of one panel (contiguous M x 4 chunk)
+// ---------------------------------------------------------------------------------------------
+template <int LOGM>
+struct PanelGeom {
+    static constexpr int T = Steps<LOGM>::T;
+    static constexpr int G = T >= 512 ? 1 : (T >= 256 ? 2 : 4);  // panels per workgroup
+    static constexpr int THREADS = T * G;
+    // persistent pipelined kernel: two register sets, one workgroup per CU for 512 threads
+    static constexpr int PIPE_WAVES_PER_SIMD = THREADS >= 1024 ? 4 : (THREADS >= 512 ? 2 : 1);
+    static constexpr int PIPE_WG_PER_CU = THREADS >= 512 ? 1 : 512 / THREADS;
+    static constexpr int WAVES_PER_SIMD = THREADS >= 512 ? 4 : 1;
+};
+
+// element offsets inside a panel: row m -> m*4 ; the uniform part (q) stays in SGPRs
+template <class Core>
+__device__ __forceinline__ void panel_load_in(const float2* __restrict__ pbase, int tid, float2 (&d)[4][8]) {
+#pragma unroll
+    for (int u = 0; u < Core::NU0; ++u) {
+        const unsigned toff = (unsigned)(tid + u * Core::T) * 4u;
+#pragma unroll
+        for (int q = 0; q < Core::RHO0; ++q) {
+            const int s = u * Core::RHO0 + q;
+            load4(pbase + ((size_t)(q << Core::LOGR0) * 4) + toff, d[0][s], d[1][s], d[2][s], d[3][s]);
+        }
+    }
+}
+template <class Core>
+__device__ __forceinline__ void panel_load_out(const float2* __restrict__ pbase, int tid, float2 (&d)[4][8]) {
+#pragma unroll
+    for (int u = 0; u < Core::NUL; ++u) {
+        const unsigned toff = (unsigned)(tid + u * Core::T) * 4u;
+#pragma unroll
+        for (int q = 0; q < Core::RHOL; ++q) {
+            const int s = u * Core::RHOL + q;
+            load4(pbase + ((size_t)(q << Core::LOGOUT) * 4) + toff, d[0][s], d[1][s], d[2][s], d[3][s]);
+        }
+    }
+}
+template <class Core>
+__device__ __forceinline__ void panel_store_out(float2* __restrict__ pbase, int tid, const float2 (&d)[4][8]) {
+#pragma unroll
+    for (int u = 0; u < Core::NUL; ++u) {
+        const unsigned toff = (unsigned)(tid + u * Core::T) * 4u;
+#pragma unroll
+        for (int q = 0; q < Core::RHOL; ++q) {
+            const int s = u * Core::RHOL + q;
+            store4(pbase + ((size_t)(q << Core::LOGOUT) * 4) + toff, d[0][s], d[1][s], d[2][s], d[3][s]);
+        }
+    }
+}
+
+// last-step result order -> first-step operand order through LDS when the two radices differ
+template <int LOGM, class Core, int SEQ>
+__device__ __forceinline__ void redistribute(float2 (&cur)[4][8], float2* grp_lds, int tid) {
+    using St = Steps<LOGM>;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        float2* buf = grp_lds + ((SEQ + b) & 1) * St::BUF;
+#pragma unroll
+        for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+            for (int q = 0; q < Core::RHOL; ++q) buf[Core::out_index(tid, u, q)] = cur[b][u * Core::RHOL + q];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+            for (int q = 0; q < Core::RHO0; ++q) cur[b][u * Core::RHO0 + q] = buf[Core::in_index(tid, u, q)];
+    }
+}
+
+// forward column FFT of every panel, in place (PSF spectrum)
+template <int LOGM>
+__global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PER_SIMD) void fft_cols_panel_fwd_kernel(
+    float2* __restrict__ data, const float2* __restrict__ tw_fwd, const int M, const int npanels) {
+    using St = Steps<LOGM>;
+    using Geo = PanelGeom<LOGM>;
+    constexpr int G = Geo::G, T = St::T;
+    using Core = FftCore<LOGM, 4, 2, PolicyFast>;
+    __shared__ float2 lds[G * 2 * St::BUF];
+    const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
+    const int p = blockIdx.x * G + g;
+    const bool active = p < npanels;
+    float2* pbase = data + (size_t)(active ? p : 0) * M * 4;
+    typename Core::Bases bases;
+    Core::init_bases(bases, tw_fwd, tid);
+    float2 v[4][8];
+    panel_load_in<Core>(pbase, tid, v);
+    Core::template run<0, false>(v, lds + g * 2 * St::BUF, tw_fwd, bases, tid);
+    if (active) panel_store_out<Core>(pbase, tid, v);
+}
+
+// One panel of pass B' on register set `cur` (spectrum, first-step order) with the filter in `flt`
+// (last-step order): forward, multiply, then -- `flt` now free -- queue the NEXT panel's spectrum
+// into it, inverse, store, and queue the next panel's filter into `cur`.
+template <int LOGM, class Core>
+__device__ __forceinline__ void panel_tile(float2 (&cur)[4][8], float2 (&flt)[4][8], float2* __restrict__ data,
+                                           const float2* __restrict__ filt, float2* grp_lds, const typename Core::Bases& bases,
+                                           const float2* __restrict__ tw_fwd, int tid, size_t poff, bool store_ok,
+                                           bool have_next, size_t next_poff) {
+    Core::template run<0, false>(cur, grp_lds, tw_fwd, bases, tid);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        cur[0][s] = cmul_fma(cur[0][s], flt[0][s]);
+        cur[1][s] = cmul_fma(cur[1][s], flt[1][s]);
+        cur[2][s] = cmul_fma(cur[2][s], flt[2][s]);
+        cur[3][s] = cmul_fma(cur[3][s], flt[3][s]);
+    }
+    if (have_next) panel_load_in<Core>(data + next_poff, tid, flt);
+    constexpr int SEQ1 = Core::SLOTS;
+    if constexpr (Core::RHOL != Core::RHO0) {
+        redistribute<LOGM, Core, SEQ1>(cur, grp_lds, tid);
+        Core::template run<SEQ1 + 4, true>(cur, grp_lds, tw_fwd, bases, tid);
+    } else {
+        Core::template run<SEQ1, true>(cur, grp_lds, tw_fwd, bases, tid);
+    }
+    if (store_ok) panel_store_out<Core>(data + poff, tid, cur);
+    if (have_next) panel_load_out<Core>(filt + next_poff, tid, cur);
+}
+
+template <int LOGM>
+__global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::PIPE_WAVES_PER_SIMD) void fft_cols_panel_fused_kernel(
+    float2* __restrict__ data, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const int M,
+    const int npanels, const int ntiles) {
+    using St = Steps<LOGM>;
+    using Geo = PanelGeom<LOGM>;
+    constexpr int G = Geo::G, T = St::T;
+    using Core = FftCore<LOGM, 4, 2, PolicyFast>;
+    __shared__ float2 lds[G * 2 * St::BUF];
+    const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
+    float2* grp_lds = lds + g * 2 * St::BUF;
+    int t = blockIdx.x;
+    if (t >= ntiles) return;  // uniform over the workgroup
+
+    typename Core::Bases bases;
+    Core::init_bases(bases, tw_fwd, tid);
+
+    const size_t pstride = (size_t)M * 4;
+    auto poff_of = [&](int tile, bool& ok) {
+        const int p = tile * G + g;
+        ok = p < npanels;
+        return (size_t)(ok ? p : 0) * pstride;  // out-of-range groups read panel 0, store nothing
+    };
+
+    float2 P[4][8], Q[4][8];
+    bool ok;
+    size_t poff = poff_of(t, ok);
+    panel_load_in<Core>(data + poff, tid, P);
+    panel_load_out<Core>(filt + poff, tid, Q);
+    while (true) {
+        int tn = t + gridDim.x;
+        bool more = tn < ntiles, nok = false;
+        size_t npoff = more ? poff_of(tn, nok) : 0;
+        panel_tile<LOGM, Core>(P, Q, data, filt, grp_lds, bases, tw_fwd, tid, poff, ok, more, npoff);
+        if (!more) break;
+        t = tn; poff = npoff; ok = nok;
+        tn = t + gridDim.x;
+        more = tn < ntiles;
+        npoff = more ? poff_of(tn, nok) : 0;
+        panel_tile<LOGM, Core>(Q, P, data, filt, grp_lds, bases, tw_fwd, tid, poff, ok, more, npoff);
+        if (!more) break;
+        t = tn; poff = npoff; ok = nok;
+    }
+}
+
+template <int LOGM>
+static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const float2* tw, hipStream_t s) {
+    using Geo = PanelGeom<LOGM>;
+    const int M = 1 << LOGM;
+    const int npanels = a.N / 4;
+    const int ntiles = (npanels + Geo::G - 1) / Geo::G;
+    if (kind == COL_FWD) {
+        hipLaunchKernelGGL((fft_cols_panel_fwd_kernel<LOGM>), dim3(ntiles), dim3(Geo::THREADS), 0, s, a.data, tw, M, npanels);
+    } else if (kind == COL_FUSED) {
+        int grid = (a.num_cu > 0 ? a.num_cu : 256) * Geo::PIPE_WG_PER_CU;
+        if (a.no_pipeline || grid > ntiles) grid = ntiles;
+        hipLaunchKernelGGL((fft_cols_panel_fused_kernel<LOGM>), dim3(grid), dim3(Geo::THREADS), 0, s, a.data, a.filt, tw, M,
+                           npanels, ntiles);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_cols_panel(int logm, ColKind kind, const ColArgs& a, const float2* tw_fwd, hipStream_t s) {
+    FDR_DISPATCH_LOG(logm, launch_cols_panel_t<LG>(kind, a, tw_fwd, s));
+    return hipErrorInvalidValue;
+}
+
+}  // namespace fdr
