@@ -49,6 +49,9 @@ extern "C" {
 #define FDR_FLAG_ROWMAJOR 4u    /* fast mode: keep the intermediate spectrum row-major (32-byte column
                                    tiles) instead of panel-major; slower, kept for A/B measurements   */
 
+#define FDR_FLAG_NO_PACKING 8u  /* fast mode: one complex row transform per row instead of two real /
+                                   Hermitian rows per transform (A/B measurements)                    */
+
 /* normalisation area selector for fdr_wiener_* */
 #define FDR_NORM_PADDED 1  /* serial semantics: min/max over the padded M x N area, then crop
                               (serial.cpp:36-38 + fft/fft_serial.cpp:243-246)                 */

@@ -106,6 +106,7 @@ struct fdr_plan {
     bool simple = false;
     int num_cu = 256;
     int no_pipeline = 0;
+    int no_packing = 0;
     bool panel = false;  // fast mode: panel-major intermediate spectrum and filter
     float2 *tw_row_f = nullptr, *tw_row_i = nullptr, *tw_col_f = nullptr, *tw_col_i = nullptr;
     float2* work = nullptr;   // M x N complex working spectrum
@@ -187,7 +188,7 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
     } else if (p->panel) {
         RowArgs ra{};
         ra.src_real = d_psf; ra.src_rows = prows; ra.src_cols = pcols; ra.src_stride = pstride;
-        ra.dst_c = p->filt; ra.M = p->M;
+        ra.dst_c = p->filt; ra.M = p->M; ra.no_packing = p->no_packing;
         FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, ra, p->tw_row_f, s));
         ColArgs ca{};
         ca.data = p->filt; ca.N = p->N; ca.num_cu = p->num_cu;
@@ -260,7 +261,7 @@ int wiener_dev_impl(fdr_plan* p, const float* d_img, int rows, int cols, int str
             ScopedPass t(p, s, kPassRowsFwd);
             RowArgs a{};
             a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
-            a.dst_c = p->work; a.M = p->M;
+            a.dst_c = p->work; a.M = p->M; a.no_packing = p->no_packing;
             FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
         }
         {   // B': per panel, columns forward * W * inverse, persistent + register double-buffered
@@ -272,7 +273,7 @@ int wiener_dev_impl(fdr_plan* p, const float* d_img, int rows, int cols, int str
         {   // C': 4 rows gathered from the panels, inverse, real plane, min/max
             ScopedPass t(p, s, kPassRowsInvReal);
             RowArgs a{};
-            a.src_c = p->work; a.dst_real = p->raw; a.mm_part = p->mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
+            a.src_c = p->work; a.dst_real = p->raw; a.mm_part = p->mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M; a.no_packing = p->no_packing;
             FDR_HIP(launch_rows4(p->logN, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, a, p->tw_row_f, s));
             n_part = rows4_minmax_partials(p->logN, p->M);
         }
@@ -301,8 +302,12 @@ int wiener_dev_impl(fdr_plan* p, const float* d_img, int rows, int cols, int str
     {   // E: normalise to [0,1] and crop (fft/fft_serial.cpp:246, serial.cpp:38)
         ScopedPass t(p, s, kPassNormalize);
         if (n_part <= 0 || n_part > p->mm_part_cap) return fail(FDR_ERR_STATE, "fdr_wiener: min/max partial count out of range");
-        FDR_HIP(launch_reduce_minmax(p->mm_part, n_part, p->mm, s));
-        FDR_HIP(launch_normalize(p->raw, p->N, p->mm, d_out, rows, cols, out_stride, p->mode, s));
+        if (n_part <= 4096) {
+            FDR_HIP(launch_normalize(p->raw, p->N, p->mm_part, n_part, nullptr, d_out, rows, cols, out_stride, s));
+        } else {  // many partials (reference-shaped path): fold them once in a separate launch
+            FDR_HIP(launch_reduce_minmax(p->mm_part, n_part, p->mm, s));
+            FDR_HIP(launch_normalize(p->raw, p->N, nullptr, 0, p->mm, d_out, rows, cols, out_stride, s));
+        }
     }
     return FDR_OK;
 }
@@ -345,6 +350,7 @@ int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan
     p->device = device; p->M = M; p->N = N; p->logM = ilog2(M); p->logN = ilog2(N); p->mode = mode; p->flags = flags;
     p->simple = (flags & FDR_FLAG_SIMPLE_PATH) != 0 || M < 8 || N < 8;
     p->no_pipeline = (flags & FDR_FLAG_NO_PIPELINE) != 0;
+    p->no_packing = (flags & FDR_FLAG_NO_PACKING) != 0;
     p->panel = mode == FDR_MODE_FAST && !p->simple && (flags & FDR_FLAG_ROWMAJOR) == 0;
     {
         int cus = 0;

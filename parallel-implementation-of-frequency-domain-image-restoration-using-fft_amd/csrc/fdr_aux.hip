@@ -204,26 +204,79 @@ hipError_t launch_reduce_minmax(const float2* mm_part, int n_part, float* mm, hi
 // ---- cv::normalize(src, dst, 0, 1, NORM_MINMAX) (fft/fft_serial.cpp:246) + crop (serial.cpp:38) ----
 // scale/shift exactly as OpenCV 4.x derives them for CV_32F: double min/max, scale rounded to
 // float, shift = (float)dmin - (float)(smin*scale); applied as a float multiply then a float add.
-__global__ void normalize_kernel(const float* __restrict__ raw, int N, const float* __restrict__ mm,
-                                 float* __restrict__ out, int rows, int cols, int out_stride) {
-    const double smin = (double)mm[0], smax = (double)mm[1];
+// Every workgroup first folds the (few thousand) per-workgroup min/max partials itself -- a fixed
+// order, so the result is deterministic -- which saves a separate reduce launch (~4.4 us).
+__device__ __forceinline__ void minmax_to_scale_shift(float mn, float mx, float& fscale, float& fshift) {
+    const double smin = (double)mn, smax = (double)mx;
     double scale = ((smax - smin) > 2.2204460492503131e-16) ? 1.0 / (smax - smin) : 0.0;
     scale = (double)(float)scale;
-    const float fscale = (float)scale;
-    const float fshift = 0.0f - (float)(smin * scale);
-    const int y = blockIdx.y;
-    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < cols; x += gridDim.x * blockDim.x) {
-        const float p = raw[(size_t)y * N + x] * fscale;
-        out[(size_t)y * out_stride + x] = p + fshift;
+    fscale = (float)scale;
+    fshift = 0.0f - (float)(smin * scale);
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ raw, int N, const float2* __restrict__ part,
+                                                        int n_part, const float* __restrict__ mm, float* __restrict__ out,
+                                                        int rows, int cols, int out_stride) {
+    __shared__ float2 red[4];
+    float mn, mx;
+    if (part != nullptr) {
+        mn = __builtin_inff(); mx = -__builtin_inff();
+        for (int i = threadIdx.x; i < n_part; i += 256) {
+            const float2 p = part[i];
+            mn = fminf(mn, p.x);
+            mx = fmaxf(mx, p.y);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn = fminf(mn, __shfl_xor(mn, off));
+            mx = fmaxf(mx, __shfl_xor(mx, off));
+        }
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = make_float2(mn, mx);
+        __syncthreads();
+        mn = fminf(fminf(red[0].x, red[1].x), fminf(red[2].x, red[3].x));
+        mx = fmaxf(fmaxf(red[0].y, red[1].y), fmaxf(red[2].y, red[3].y));
+    } else {
+        mn = mm[0]; mx = mm[1];
+    }
+    float fscale, fshift;
+    minmax_to_scale_shift(mn, mx, fscale, fshift);
+
+    constexpr int W = VEC4 ? 1024 : 256;               // elements per workgroup per segment
+    const int segs_per_row = (cols + W - 1) / W;
+    const long long nseg = (long long)rows * segs_per_row;
+    for (long long sgi = blockIdx.x; sgi < nseg; sgi += gridDim.x) {
+        const int y = (int)(sgi / segs_per_row);
+        const int x = (int)(sgi % segs_per_row) * W + threadIdx.x * (VEC4 ? 4 : 1);
+        if (VEC4) {
+            if (x < cols) {  // cols % 4 == 0
+                const float4 v = *reinterpret_cast<const float4*>(raw + (size_t)y * N + x);
+                float4 o;
+                o.x = v.x * fscale; o.y = v.y * fscale; o.z = v.z * fscale; o.w = v.w * fscale;
+                o.x = o.x + fshift; o.y = o.y + fshift; o.z = o.z + fshift; o.w = o.w + fshift;
+                *reinterpret_cast<float4*>(out + (size_t)y * out_stride + x) = o;
+            }
+        } else {
+            if (x < cols) {
+                const float p = raw[(size_t)y * N + x] * fscale;
+                out[(size_t)y * out_stride + x] = p + fshift;
+            }
+        }
     }
 }
 
-hipError_t launch_normalize(const float* raw, int N, const float* mm, float* out, int rows, int cols, int out_stride,
-                            int /*mode*/, hipStream_t s) {
+hipError_t launch_normalize(const float* raw, int N, const float2* mm_part, int n_part, const float* mm, float* out,
+                            int rows, int cols, int out_stride, hipStream_t s) {
     if (rows <= 0 || cols <= 0) return hipSuccess;
-    int gx = (cols + 255) / 256;
-    if (gx > 16) gx = 16;
-    hipLaunchKernelGGL(normalize_kernel, dim3(gx, rows), dim3(256), 0, s, raw, N, mm, out, rows, cols, out_stride);
+    const bool vec4 = (cols % 4 == 0) && (out_stride % 4 == 0) && (N % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && ((reinterpret_cast<uintptr_t>(raw) & 15) == 0);
+    const int W = vec4 ? 1024 : 256;
+    long long nseg = (long long)rows * ((cols + W - 1) / W);
+    int grid = nseg > 2048 ? 2048 : (int)nseg;
+    if (vec4)
+        hipLaunchKernelGGL(normalize_kernel<true>, dim3(grid), dim3(256), 0, s, raw, N, mm_part, n_part, mm, out, rows, cols, out_stride);
+    else
+        hipLaunchKernelGGL(normalize_kernel<false>, dim3(grid), dim3(256), 0, s, raw, N, mm_part, n_part, mm, out, rows, cols, out_stride);
     return hipGetLastError();
 }
 

@@ -28,6 +28,7 @@ struct RowArgs {
     float2* mm_part;  // one (min, max) partial per workgroup
     int mm_rows, mm_cols;
     int M;              // number of rows to transform
+    int no_packing;     // rows4 kernels: one complex transform per row instead of two rows per transform
 };
 
 struct ColArgs {
@@ -69,8 +70,9 @@ hipError_t launch_reduce_minmax(const float2* mm_part, int n_part, float* mm, hi
 // number of (min,max) partials the row / column real-output passes write for an M x N plan
 int rows_minmax_partials(int logl, int M);
 int cols_minmax_partials(int logm, int N);
-hipError_t launch_normalize(const float* raw, int N, const float* mm, float* out, int rows, int cols, int out_stride,
-                            int mode, hipStream_t s);
+// mm_part != nullptr: every workgroup folds the n_part partials itself; else mm = {min, max} from launch_reduce_minmax
+hipError_t launch_normalize(const float* raw, int N, const float2* mm_part, int n_part, const float* mm, float* out,
+                            int rows, int cols, int out_stride, hipStream_t s);
 hipError_t launch_psf_motion(int size, double angle_deg, float* d_out, hipStream_t s);
 hipError_t launch_synth(uint64_t seed, uint64_t first, size_t count, float* d_out, hipStream_t s);
 hipError_t launch_dft_naive(const float2* src, float2* dst, int n, int inverse, hipStream_t s);

@@ -112,17 +112,158 @@ __global__ __launch_bounds__(Rows4Geom<LOGL>::THREADS, Rows4Geom<LOGL>::WAVES_PE
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-for-one row transforms (fast mode only; rounding differs from the serial path at the 1e-7
+// level, far inside the 1e-4 budget).  The image rows are real, and after the inverse column pass
+// every row spectrum is Hermitian, so two rows share one complex transform:
+//   forward : z = x_a + i x_b  ->  Z = FFT(z);  X_a[n] = (Z[n] + conj Z[N-n]) / 2,
+//                                               X_b[n] = (Z[n] - conj Z[N-n]) / (2i)
+//             (Z[N-n] lives in another thread: one natural-order LDS round trip)
+//   inverse : Z = Y_a + i Y_b  ->  z = IFFT(Z);  row a = Re z, row b = Im z   (no fix-up at all)
+// A 4-row group therefore costs 2 complex transforms instead of 4.
+// ---------------------------------------------------------------------------------------------
+template <int LOGL>
+struct Rows4PackGeom {
+    static constexpr int T = Steps<LOGL>::T;
+    static constexpr int G = T >= 256 ? 1 : 256 / T;
+    static constexpr int THREADS = T * G;
+};
+
+template <int LOGL>
+__global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_packed_kernel(const RowArgs a,
+                                                                                          const float2* __restrict__ tw_fwd) {
+    using St = Steps<LOGL>;
+    using Geo = Rows4PackGeom<LOGL>;
+    constexpr int G = Geo::G, T = St::T, L = St::L;
+    using Core = FftCore<LOGL, 2, 2, PolicyFast>;
+    __shared__ float2 lds[G * 2 * St::BUF];
+    const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
+    float2* grp_lds = lds + g * 2 * St::BUF;
+    const int M = a.M;
+    const int r0 = (blockIdx.x * G + g) * 4;
+    const bool active = r0 < M;
+    const int rr = active ? r0 : 0;
+
+    typename Core::Bases bases;
+    Core::init_bases(bases, tw_fwd, tid);
+
+    float2 z[2][8];
+#pragma unroll
+    for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+        for (int q = 0; q < Core::RHO0; ++q) {
+            const int s = u * Core::RHO0 + q;
+            const int n = Core::in_index(tid, u, q);
+            float x[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                x[b] = 0.f;
+                if (rr + b < a.src_rows && n < a.src_cols) x[b] = a.src_real[(size_t)(rr + b) * a.src_stride + n];
+            }
+            z[0][s] = make_float2(x[0], x[1]);
+            z[1][s] = make_float2(x[2], x[3]);
+        }
+
+    Core::template run<0, false>(z, grp_lds, tw_fwd, bases, tid);
+
+    // separate the two real rows of each packed transform and store all four spectra panel-major
+    constexpr int SEQ1 = Core::SLOTS;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        float2* buf = grp_lds + ((SEQ1 + b) & 1) * St::BUF;
+#pragma unroll
+        for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+            for (int q = 0; q < Core::RHOL; ++q) buf[Core::out_index(tid, u, q)] = z[b][u * Core::RHOL + q];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+            for (int q = 0; q < Core::RHOL; ++q) {
+                const int s = u * Core::RHOL + q;
+                const int n = Core::out_index(tid, u, q);
+                const float2 zn = z[b][s];
+                const float2 zm = buf[(L - n) & (L - 1)];
+                const float2 xa = make_float2(0.5f * (zn.x + zm.x), 0.5f * (zn.y - zm.y));
+                const float2 xb = make_float2(0.5f * (zn.y + zm.y), 0.5f * (zm.x - zn.x));
+                if (active) {
+                    float2* p = a.dst_c + ((size_t)(n >> 2) * M + r0 + 2 * b) * 4 + (n & 3);
+                    p[0] = xa;
+                    p[4] = xb;
+                }
+            }
+    }
+}
+
+template <int LOGL>
+__global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_packed_kernel(const RowArgs a,
+                                                                                          const float2* __restrict__ tw_fwd) {
+    using St = Steps<LOGL>;
+    using Geo = Rows4PackGeom<LOGL>;
+    constexpr int G = Geo::G, T = St::T, L = St::L;
+    using Core = FftCore<LOGL, 2, 2, PolicyFast>;
+    __shared__ float2 lds[G * 2 * St::BUF];
+    const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
+    const int M = a.M;
+    const int r0 = (blockIdx.x * G + g) * 4;
+    const bool active = r0 < M;
+    const int rr = active ? r0 : 0;
+
+    typename Core::Bases bases;
+    Core::init_bases(bases, tw_fwd, tid);
+
+    float2 z[2][8];
+#pragma unroll
+    for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+        for (int q = 0; q < Core::RHO0; ++q) {
+            const int s = u * Core::RHO0 + q;
+            const int n = Core::in_index(tid, u, q);
+            const float2* p = a.src_c + ((size_t)(n >> 2) * M + rr) * 4 + (n & 3);
+            const float2 y0 = p[0], y1 = p[4], y2 = p[8], y3 = p[12];
+            z[0][s] = make_float2(y0.x - y1.y, y0.y + y1.x);  // Y_a + i Y_b
+            z[1][s] = make_float2(y2.x - y3.y, y2.y + y3.x);
+        }
+
+    Core::template run<0, true>(z, lds + g * 2 * St::BUF, tw_fwd, bases, tid);
+
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    if (active) {
+#pragma unroll
+        for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+            for (int q = 0; q < Core::RHOL; ++q) {
+                const int s = u * Core::RHOL + q;
+                const int n = Core::out_index(tid, u, q);
+                const float r[4] = {z[0][s].x, z[0][s].y, z[1][s].x, z[1][s].y};
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    a.dst_real[(size_t)(r0 + b) * L + n] = r[b];
+                    if (r0 + b < a.mm_rows && n < a.mm_cols) {
+                        mn = fminf(mn, r[b]);
+                        mx = fmaxf(mx, r[b]);
+                    }
+                }
+            }
+    }
+    block_minmax_store(mn, mx, a.mm_part);
+}
+
 template <int LOGL>
 static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const float2* tw, hipStream_t s) {
     using Geo = Rows4Geom<LOGL>;
     const int groups = (a.M + 3) / 4;
     const dim3 grid((groups + Geo::G - 1) / Geo::G), block(Geo::THREADS);
-    if (in == ROW_IN_REAL && out == ROW_OUT_COMPLEX)
-        hipLaunchKernelGGL((fft_rows4_kernel<LOGL, ROW_IN_REAL, ROW_OUT_COMPLEX, false>), grid, block, 0, s, a, tw);
-    else if (in == ROW_IN_COMPLEX && out == ROW_OUT_REAL_MINMAX)
-        hipLaunchKernelGGL((fft_rows4_kernel<LOGL, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, true>), grid, block, 0, s, a, tw);
-    else
+    static_assert(Rows4PackGeom<LOGL>::G == Geo::G && Rows4PackGeom<LOGL>::THREADS == Geo::THREADS, "same launch shape");
+    if (in == ROW_IN_REAL && out == ROW_OUT_COMPLEX) {
+        if (a.no_packing) hipLaunchKernelGGL((fft_rows4_kernel<LOGL, ROW_IN_REAL, ROW_OUT_COMPLEX, false>), grid, block, 0, s, a, tw);
+        else hipLaunchKernelGGL((fft_rows4_fwd_packed_kernel<LOGL>), grid, block, 0, s, a, tw);
+    } else if (in == ROW_IN_COMPLEX && out == ROW_OUT_REAL_MINMAX) {
+        if (a.no_packing) hipLaunchKernelGGL((fft_rows4_kernel<LOGL, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, true>), grid, block, 0, s, a, tw);
+        else hipLaunchKernelGGL((fft_rows4_inv_packed_kernel<LOGL>), grid, block, 0, s, a, tw);
+    } else {
         return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
