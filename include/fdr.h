@@ -52,6 +52,8 @@ extern "C" {
 #define FDR_FLAG_NO_PACKING 8u  /* fast mode: one complex row transform per row instead of two real /
                                    Hermitian rows per transform (A/B measurements)                    */
 
+#define FDR_FLAG_POW2_PANELS 16u /* fast mode: panel stride exactly 4*M elements (no channel skew; A/B) */
+
 /* normalisation area selector for fdr_wiener_* */
 #define FDR_NORM_PADDED 1  /* serial semantics: min/max over the padded M x N area, then crop
                               (serial.cpp:36-38 + fft/fft_serial.cpp:243-246)                 */

@@ -107,7 +107,8 @@ struct fdr_plan {
     int num_cu = 256;
     int no_pipeline = 0;
     int no_packing = 0;
-    bool panel = false;  // fast mode: panel-major intermediate spectrum and filter
+    bool panel = false;
+    size_t pstride = 0;  // panel stride (float2 elements)  // fast mode: panel-major intermediate spectrum and filter
     float2 *tw_row_f = nullptr, *tw_row_i = nullptr, *tw_col_f = nullptr, *tw_col_i = nullptr;
     float2* work = nullptr;   // M x N complex working spectrum
     float2* work2 = nullptr;  // simple path: N x M transpose buffer
@@ -188,10 +189,10 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
     } else if (p->panel) {
         RowArgs ra{};
         ra.src_real = d_psf; ra.src_rows = prows; ra.src_cols = pcols; ra.src_stride = pstride;
-        ra.dst_c = p->filt; ra.M = p->M; ra.no_packing = p->no_packing;
+        ra.dst_c = p->filt; ra.M = p->M; ra.no_packing = p->no_packing; ra.pstride = p->pstride;
         FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, ra, p->tw_row_f, s));
         ColArgs ca{};
-        ca.data = p->filt; ca.N = p->N; ca.num_cu = p->num_cu;
+        ca.data = p->filt; ca.N = p->N; ca.num_cu = p->num_cu; ca.pstride = p->pstride;
         FDR_HIP(launch_cols_panel(p->logM, COL_FWD, ca, p->tw_col_f, s));
     } else {
         RowArgs ra{};
@@ -203,7 +204,7 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
         FDR_HIP(launch_cols(p->logM, p->mode, COL_FWD, ca, p->tw_col_f, p->tw_col_i, s));
     }
     if (p->mode == FDR_MODE_FAST)
-        FDR_HIP(launch_make_filter_fast(p->filt, p->filt, (size_t)p->M * p->N, K, s));
+        FDR_HIP(launch_make_filter_fast(p->filt, p->filt, p->panel ? (size_t)(p->N / 4) * p->pstride : (size_t)p->M * p->N, K, s));
     p->K = K;
     p->have_psf = true;
     return FDR_OK;
@@ -261,19 +262,19 @@ int wiener_dev_impl(fdr_plan* p, const float* d_img, int rows, int cols, int str
             ScopedPass t(p, s, kPassRowsFwd);
             RowArgs a{};
             a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
-            a.dst_c = p->work; a.M = p->M; a.no_packing = p->no_packing;
+            a.dst_c = p->work; a.M = p->M; a.no_packing = p->no_packing; a.pstride = p->pstride;
             FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
         }
         {   // B': per panel, columns forward * W * inverse, persistent + register double-buffered
             ScopedPass t(p, s, kPassColsFused);
             ColArgs c{};
-            c.data = p->work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu; c.no_pipeline = p->no_pipeline;
+            c.data = p->work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu; c.no_pipeline = p->no_pipeline; c.pstride = p->pstride;
             FDR_HIP(launch_cols_panel(p->logM, COL_FUSED, c, p->tw_col_f, s));
         }
         {   // C': 4 rows gathered from the panels, inverse, real plane, min/max
             ScopedPass t(p, s, kPassRowsInvReal);
             RowArgs a{};
-            a.src_c = p->work; a.dst_real = p->raw; a.mm_part = p->mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M; a.no_packing = p->no_packing;
+            a.src_c = p->work; a.dst_real = p->raw; a.mm_part = p->mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M; a.no_packing = p->no_packing; a.pstride = p->pstride;
             FDR_HIP(launch_rows4(p->logN, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, a, p->tw_row_f, s));
             n_part = rows4_minmax_partials(p->logN, p->M);
         }
@@ -356,7 +357,11 @@ int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) p->num_cu = cus;
     }
-    const size_t P = (size_t)M * N;
+    size_t P = (size_t)M * N;
+    if (p->panel) {  // panel-major buffers: N/4 panels of PS elements
+        p->pstride = (size_t)M * 4 + ((flags & FDR_FLAG_POW2_PANELS) ? 0 : 16);
+        P = (size_t)(N / 4) * p->pstride;
+    }
     std::vector<float2> t;
     int rc = FDR_OK;
     build_twiddles(N, mode, false, t); if ((rc = upload(&p->tw_row_f, t)) != FDR_OK) goto bad;

@@ -6,9 +6,11 @@
 // the transform compiled out still took 191 us at 4096^2 (2.1 TB/s algorithmic, each line moved
 // ~4x).  The fix is a layout in which every pass moves whole lines:
 //
-//     panel_index(m, n) = ((n >> 2) * M + m) * 4 + (n & 3)        (M rows, N columns, float2)
+//     panel_index(m, n) = (n >> 2) * PS + m * 4 + (n & 3)     (M rows, N columns, float2 elements)
 //
-// i.e. panels of 4 columns, each panel a contiguous M x 4 array.  A column tile (4 columns, all
+// i.e. panels of 4 columns, each panel a contiguous M x 4 array; the panel stride PS = 4 M + 16 is
+// deliberately not a power of two, so the 128-byte lines a row workgroup scatters over all panels
+// do not all fall on the same memory channel.  A column tile (4 columns, all
 // rows) is then ONE contiguous 32*M-byte chunk, and a row workgroup that owns 4 consecutive rows
 // writes / reads complete 128-byte lines (4 rows x 4 columns) in every panel.
 //
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(Rows4Geom<LOGL>::THREADS, Rows4Geom<LOGL>::WAVES_PE
                     v[b][s] = make_float2(x, 0.f);
                 }
             } else {
-                const float2* p = a.src_c + ((size_t)(n >> 2) * M + rr) * 4 + (n & 3);
+                const float2* p = a.src_c + (size_t)(n >> 2) * a.pstride + (size_t)rr * 4 + (n & 3);
 #pragma unroll
                 for (int b = 0; b < B; ++b) v[b][s] = p[b * 4];
             }
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(Rows4Geom<LOGL>::THREADS, Rows4Geom<LOGL>::WAVES_PE
                 for (int q = 0; q < Core::RHOL; ++q) {
                     const int s = u * Core::RHOL + q;
                     const int n = Core::out_index(tid, u, q);
-                    float2* p = a.dst_c + ((size_t)(n >> 2) * M + r0) * 4 + (n & 3);
+                    float2* p = a.dst_c + (size_t)(n >> 2) * a.pstride + (size_t)r0 * 4 + (n & 3);
 #pragma unroll
                     for (int b = 0; b < B; ++b) p[b * 4] = v[b][s];
                 }
@@ -148,50 +150,102 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
     Core::init_bases(bases, tw_fwd, tid);
 
     float2 z[2][8];
+    // common case first: all four rows and all L columns inside the image -> 32 unpredicated loads
+    // from four wave-uniform row bases with one 32-bit per-thread offset
+    const bool interior = (rr + 3 < a.src_rows) && (a.src_cols >= L);
+    if (interior) {
+        const float* row0 = a.src_real + (size_t)rr * a.src_stride;
+        const float* row1 = row0 + a.src_stride;
+        const float* row2 = row1 + a.src_stride;
+        const float* row3 = row2 + a.src_stride;
 #pragma unroll
-    for (int u = 0; u < Core::NU0; ++u)
+        for (int u = 0; u < Core::NU0; ++u)
 #pragma unroll
-        for (int q = 0; q < Core::RHO0; ++q) {
-            const int s = u * Core::RHO0 + q;
-            const int n = Core::in_index(tid, u, q);
-            float x[4];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                x[b] = 0.f;
-                if (rr + b < a.src_rows && n < a.src_cols) x[b] = a.src_real[(size_t)(rr + b) * a.src_stride + n];
+            for (int q = 0; q < Core::RHO0; ++q) {
+                const int s = u * Core::RHO0 + q;
+                const unsigned n = (unsigned)Core::in_index(tid, u, q);
+                z[0][s] = make_float2(row0[n], row1[n]);
+                z[1][s] = make_float2(row2[n], row3[n]);
             }
-            z[0][s] = make_float2(x[0], x[1]);
-            z[1][s] = make_float2(x[2], x[3]);
-        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+            for (int q = 0; q < Core::RHO0; ++q) {
+                const int s = u * Core::RHO0 + q;
+                const int n = Core::in_index(tid, u, q);
+                float x[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    x[b] = 0.f;
+                    if (rr + b < a.src_rows && n < a.src_cols) x[b] = a.src_real[(size_t)(rr + b) * a.src_stride + n];
+                }
+                z[0][s] = make_float2(x[0], x[1]);
+                z[1][s] = make_float2(x[2], x[3]);
+            }
+    }
 
     Core::template run<0, false>(z, grp_lds, tw_fwd, bases, tid);
 
-    // separate the two real rows of each packed transform and store all four spectra panel-major
+    // Separate the two real rows of each packed transform and store all four spectra panel-major.
     constexpr int SEQ1 = Core::SLOTS;
+    if constexpr (T >= 4) {
+        // Both packed spectra go to LDS in natural order; then the threads re-partition the work so
+        // that a quad of lanes owns one 128-byte line (4 rows x 4 columns of a panel): lane j of the
+        // quad builds row j's four columns (32 contiguous bytes).  Every store instruction of a wave
+        // then covers 16 complete lines instead of 64 scattered 8-byte pieces.
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        float2* buf = grp_lds + ((SEQ1 + b) & 1) * St::BUF;
+        for (int b = 0; b < 2; ++b) {
+            float2* buf = grp_lds + ((SEQ1 + b) & 1) * St::BUF;
 #pragma unroll
-        for (int u = 0; u < Core::NUL; ++u)
+            for (int u = 0; u < Core::NUL; ++u)
 #pragma unroll
-            for (int q = 0; q < Core::RHOL; ++q) buf[Core::out_index(tid, u, q)] = z[b][u * Core::RHOL + q];
+                for (int q = 0; q < Core::RHOL; ++q) buf[Core::out_index(tid, u, q)] = z[b][u * Core::RHOL + q];
+        }
         __syncthreads();
+        const int j = tid & 3;                                    // row inside the 4-row group
+        const float2* buf = grp_lds + ((SEQ1 + (j >> 1)) & 1) * St::BUF;  // packed pair holding row j
+        const bool odd = (j & 1) != 0;                            // row b of the pair (else row a)
 #pragma unroll
-        for (int u = 0; u < Core::NUL; ++u)
+        for (int i = 0; i < 8; ++i) {
+            const int c = (tid >> 2) + (T / 4) * i;  // panel
+            const int n0 = c * 4;
+            float2 o[4];
 #pragma unroll
-            for (int q = 0; q < Core::RHOL; ++q) {
-                const int s = u * Core::RHOL + q;
-                const int n = Core::out_index(tid, u, q);
-                const float2 zn = z[b][s];
-                const float2 zm = buf[(L - n) & (L - 1)];
-                const float2 xa = make_float2(0.5f * (zn.x + zm.x), 0.5f * (zn.y - zm.y));
-                const float2 xb = make_float2(0.5f * (zn.y + zm.y), 0.5f * (zm.x - zn.x));
-                if (active) {
-                    float2* p = a.dst_c + ((size_t)(n >> 2) * M + r0 + 2 * b) * 4 + (n & 3);
-                    p[0] = xa;
-                    p[4] = xb;
-                }
+            for (int k = 0; k < 4; ++k) {
+                const float2 zn = buf[n0 + k];
+                const float2 zm = buf[(L - n0 - k) & (L - 1)];
+                o[k] = odd ? make_float2(0.5f * (zn.y + zm.y), 0.5f * (zm.x - zn.x))
+                           : make_float2(0.5f * (zn.x + zm.x), 0.5f * (zn.y - zm.y));
             }
+            if (active) store4(a.dst_c + (size_t)c * a.pstride + (size_t)(r0 + j) * 4, o[0], o[1], o[2], o[3]);
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float2* buf = grp_lds + ((SEQ1 + b) & 1) * St::BUF;
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) buf[Core::out_index(tid, u, q)] = z[b][u * Core::RHOL + q];
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int s = u * Core::RHOL + q;
+                    const int n = Core::out_index(tid, u, q);
+                    const float2 zn = z[b][s];
+                    const float2 zm = buf[(L - n) & (L - 1)];
+                    const float2 xa = make_float2(0.5f * (zn.x + zm.x), 0.5f * (zn.y - zm.y));
+                    const float2 xb = make_float2(0.5f * (zn.y + zm.y), 0.5f * (zm.x - zn.x));
+                    if (active) {
+                        float2* p = a.dst_c + (size_t)(n >> 2) * a.pstride + (size_t)(r0 + 2 * b) * 4 + (n & 3);
+                        p[0] = xa;
+                        p[4] = xb;
+                    }
+                }
+        }
     }
 }
 
@@ -219,7 +273,7 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_pa
         for (int q = 0; q < Core::RHO0; ++q) {
             const int s = u * Core::RHO0 + q;
             const int n = Core::in_index(tid, u, q);
-            const float2* p = a.src_c + ((size_t)(n >> 2) * M + rr) * 4 + (n & 3);
+            const float2* p = a.src_c + (size_t)(n >> 2) * a.pstride + (size_t)rr * 4 + (n & 3);
             const float2 y0 = p[0], y1 = p[4], y2 = p[8], y3 = p[12];
             z[0][s] = make_float2(y0.x - y1.y, y0.y + y1.x);  // Y_a + i Y_b
             z[1][s] = make_float2(y2.x - y3.y, y2.y + y3.x);
@@ -370,7 +424,7 @@ __device__ __forceinline__ void redistribute(float2 (&cur)[4][8], float2* grp_ld
 // forward column FFT of every panel, in place (PSF spectrum)
 template <int LOGM>
 __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PER_SIMD) void fft_cols_panel_fwd_kernel(
-    float2* __restrict__ data, const float2* __restrict__ tw_fwd, const int M, const int npanels) {
+    float2* __restrict__ data, const float2* __restrict__ tw_fwd, const size_t pstride, const int npanels) {
     using St = Steps<LOGM>;
     using Geo = PanelGeom<LOGM>;
     constexpr int G = Geo::G, T = St::T;
@@ -379,7 +433,7 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PE
     const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
     const int p = blockIdx.x * G + g;
     const bool active = p < npanels;
-    float2* pbase = data + (size_t)(active ? p : 0) * M * 4;
+    float2* pbase = data + (size_t)(active ? p : 0) * pstride;
     typename Core::Bases bases;
     Core::init_bases(bases, tw_fwd, tid);
     float2 v[4][8];
@@ -418,7 +472,7 @@ __device__ __forceinline__ void panel_tile(float2 (&cur)[4][8], float2 (&flt)[4]
 
 template <int LOGM>
 __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::PIPE_WAVES_PER_SIMD) void fft_cols_panel_fused_kernel(
-    float2* __restrict__ data, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const int M,
+    float2* __restrict__ data, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const size_t pstride,
     const int npanels, const int ntiles) {
     using St = Steps<LOGM>;
     using Geo = PanelGeom<LOGM>;
@@ -433,7 +487,6 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::PIPE_WAV
     typename Core::Bases bases;
     Core::init_bases(bases, tw_fwd, tid);
 
-    const size_t pstride = (size_t)M * 4;
     auto poff_of = [&](int tile, bool& ok) {
         const int p = tile * G + g;
         ok = p < npanels;
@@ -464,15 +517,15 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::PIPE_WAV
 template <int LOGM>
 static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const float2* tw, hipStream_t s) {
     using Geo = PanelGeom<LOGM>;
-    const int M = 1 << LOGM;
+    const size_t ps = a.pstride;
     const int npanels = a.N / 4;
     const int ntiles = (npanels + Geo::G - 1) / Geo::G;
     if (kind == COL_FWD) {
-        hipLaunchKernelGGL((fft_cols_panel_fwd_kernel<LOGM>), dim3(ntiles), dim3(Geo::THREADS), 0, s, a.data, tw, M, npanels);
+        hipLaunchKernelGGL((fft_cols_panel_fwd_kernel<LOGM>), dim3(ntiles), dim3(Geo::THREADS), 0, s, a.data, tw, ps, npanels);
     } else if (kind == COL_FUSED) {
         int grid = (a.num_cu > 0 ? a.num_cu : 256) * Geo::PIPE_WG_PER_CU;
         if (a.no_pipeline || grid > ntiles) grid = ntiles;
-        hipLaunchKernelGGL((fft_cols_panel_fused_kernel<LOGM>), dim3(grid), dim3(Geo::THREADS), 0, s, a.data, a.filt, tw, M,
+        hipLaunchKernelGGL((fft_cols_panel_fused_kernel<LOGM>), dim3(grid), dim3(Geo::THREADS), 0, s, a.data, a.filt, tw, ps,
                            npanels, ntiles);
     } else {
         return hipErrorInvalidValue;
