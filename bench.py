@@ -50,8 +50,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=4096, help="synthetic image edge (power of two)")
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--mode", choices=["fast", "parity"], default="fast")
+    ap.add_argument("--streams", type=int, default=2, help="internal streams / workspaces the batch alternates over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=0, help="edge of the CPU-baseline sample (default: --size, capped at 4096)")
     return ap.parse_args()
@@ -104,6 +105,7 @@ def main():
     flags = fdr.FLAG_NO_PIPELINE if os.environ.get("FDR_NO_PIPELINE") == "1" else 0
     plan = fdr.Plan(S, S, mode, device=local_rank, flags=flags)
     stream = torch.cuda.current_stream().cuda_stream
+    plan.set_concurrency(args.streams)
     plan.set_psf_motion(50, 30.0, 0.01, stream=stream)  # PSF generated, padded and transformed on the device
     imgs = torch.empty((B, S, S), dtype=torch.float32, device=dev)
     outs = torch.empty((B, S, S), dtype=torch.float32, device=dev)
@@ -164,7 +166,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%dx%d synthetic fp32, PSF len=50 angle=30, K=0.01, single channel, device-resident" % (S, S),
-                       "images_per_gpu_per_step": B, "mode": args.mode, "parallelism": "images sharded over %d rank(s)" % world,
+                       "images_per_gpu_per_step": B, "mode": args.mode, "streams": args.streams, "parallelism": "images sharded over %d rank(s)" % world,
                        "normalize_area": "padded (serial semantics)"},
             "roofline": roofline,
             "check": {"images_done": int(tot[0]), "checksum": tot[1], "ranks_ok": int(tot[2])},

@@ -106,6 +106,12 @@ int fdr_wiener_batch_f32_dev(fdr_plan* plan, const float* d_imgs, size_t img_pit
                              int rows, int cols, int stride,
                              float* d_out, size_t out_pitch, int out_stride, int norm_area, void* stream);
 
+/* Batched mode only: let consecutive images of fdr_wiener_batch_f32_dev alternate over `nstreams`
+ * (1..4) private workspaces on internal HIP streams, forked from / joined to the caller's stream,
+ * so one image's kernel tails overlap the next image's kernel heads.  Costs (nstreams-1) extra
+ * workspaces of 12 bytes per padded pixel.  Default 1.                                         */
+int fdr_plan_set_concurrency(fdr_plan* plan, int nstreams);
+
 /* -- fft_gpu::my_dft2D(Mat&, bool) (fft/fft.hpp:40; empty body at fft/fft_gpu.cu:515):
  *    in-place unscaled 2-D transform of M x N interleaved complex.                       */
 int fdr_fft2d_c2c(fdr_plan* plan, float* data_host, int inverse);

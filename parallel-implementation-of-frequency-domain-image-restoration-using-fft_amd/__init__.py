@@ -71,6 +71,7 @@ def _load():
     L.fdr_wiener_f32.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci]
     L.fdr_wiener_f32_dev.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, vp]
     L.fdr_wiener_batch_f32_dev.argtypes = [vp, vp, ctypes.c_size_t, ci, ci, ci, ci, vp, ctypes.c_size_t, ci, ci, vp]
+    L.fdr_plan_set_concurrency.argtypes = [vp, ci]
     L.fdr_fft2d_c2c.argtypes = [vp, vp, ci]
     L.fdr_fft2d_c2c_dev.argtypes = [vp, vp, ci, vp]
     L.fdr_fft1d_c2c.argtypes = [vp, ci, ci, ci]
@@ -80,8 +81,8 @@ def _load():
     L.fdr_plan_pass_times.argtypes = [vp, ctypes.POINTER(ci), _f32p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ci)]
     for name in ("fdr_device_count", "fdr_next_pow2", "fdr_is_pow2", "fdr_plan_create", "fdr_plan_destroy", "fdr_plan_dims",
                  "fdr_psf_motion", "fdr_psf_motion_dev", "fdr_set_psf", "fdr_set_psf_dev", "fdr_set_psf_motion",
-                 "fdr_wiener_f32", "fdr_wiener_f32_dev", "fdr_wiener_batch_f32_dev", "fdr_fft2d_c2c", "fdr_fft2d_c2c_dev",
-                 "fdr_fft1d_c2c", "fdr_dft_naive_c2c", "fdr_synth_image_dev", "fdr_plan_profile", "fdr_plan_pass_times"):
+                 "fdr_wiener_f32", "fdr_wiener_f32_dev", "fdr_wiener_batch_f32_dev", "fdr_plan_set_concurrency", "fdr_fft2d_c2c",
+                 "fdr_fft2d_c2c_dev", "fdr_fft1d_c2c", "fdr_dft_naive_c2c", "fdr_synth_image_dev", "fdr_plan_profile", "fdr_plan_pass_times"):
         getattr(L, name).restype = ci
     return L
 
@@ -91,7 +92,8 @@ lib = _load()
 EXPORTED_SYMBOLS = (
     "fdr_version", "fdr_last_error", "fdr_device_count", "fdr_next_pow2", "fdr_is_pow2", "fdr_plan_create",
     "fdr_plan_destroy", "fdr_plan_dims", "fdr_psf_motion", "fdr_psf_motion_dev", "fdr_set_psf", "fdr_set_psf_dev",
-    "fdr_set_psf_motion", "fdr_wiener_f32", "fdr_wiener_f32_dev", "fdr_wiener_batch_f32_dev", "fdr_fft2d_c2c",
+    "fdr_set_psf_motion", "fdr_wiener_f32", "fdr_wiener_f32_dev", "fdr_wiener_batch_f32_dev", "fdr_plan_set_concurrency",
+    "fdr_fft2d_c2c",
     "fdr_fft2d_c2c_dev", "fdr_fft1d_c2c", "fdr_dft_naive_c2c", "fdr_synth_image_dev", "fdr_plan_profile",
     "fdr_plan_pass_times")
 
@@ -195,6 +197,10 @@ class Plan:
         _check(lib.fdr_wiener_batch_f32_dev(self._h, ctypes.c_void_p(int(d_imgs)), img_pitch, count, rows, cols, stride,
                                             ctypes.c_void_p(int(d_out)), out_pitch, out_stride, int(norm_area),
                                             _stream(stream)))
+
+    def set_concurrency(self, nstreams):
+        """Batched mode: alternate images over `nstreams` private workspaces / internal streams."""
+        _check(lib.fdr_plan_set_concurrency(self._h, int(nstreams)))
 
     # transforms
     def fft2d(self, x, inverse=False):

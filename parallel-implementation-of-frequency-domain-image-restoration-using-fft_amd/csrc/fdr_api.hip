@@ -122,6 +122,17 @@ struct fdr_plan {
     float K = 0.f;
     bool have_psf = false;
     PassTimer timer;
+    // batched mode: images alternate over `nslots` private workspaces, each on its own internal stream,
+    // so the tail of one image's kernels overlaps the head of the next image's (slot 0 = the buffers above)
+    struct Slot {
+        float2* work = nullptr; float2* work2 = nullptr; float* raw = nullptr; float* mm = nullptr; float2* mm_part = nullptr;
+        hipStream_t stream = nullptr; hipEvent_t done = nullptr;
+    };
+    static constexpr int kMaxSlots = 4;
+    Slot slots[kMaxSlots];
+    int nslots = 1;
+    hipEvent_t fork = nullptr;
+    size_t ws_elems = 0;  // elements of one work / raw buffer
 };
 
 namespace {
@@ -157,14 +168,14 @@ int upload(float2** dst, const std::vector<float2>& v) {
 }
 
 // unscaled 2-D transform in place on d (M x N), rows then columns as fft/fft_serial.cpp:113-139
-int dft2d_dev(fdr_plan* p, float2* d, bool inverse, hipStream_t s) {
+int dft2d_dev(fdr_plan* p, float2* d, float2* work2, bool inverse, hipStream_t s) {
     const float2* twr = inverse ? p->tw_row_i : p->tw_row_f;
     const float2* twc = inverse ? p->tw_col_i : p->tw_col_f;
     if (p->simple) {
         FDR_HIP(launch_simple_rows(d, p->M, p->N, p->logN, twr, p->mode, s));
-        FDR_HIP(launch_transpose(d, p->work2, p->M, p->N, s));
-        FDR_HIP(launch_simple_rows(p->work2, p->N, p->M, p->logM, twc, p->mode, s));
-        FDR_HIP(launch_transpose(p->work2, d, p->N, p->M, s));
+        FDR_HIP(launch_transpose(d, work2, p->M, p->N, s));
+        FDR_HIP(launch_simple_rows(work2, p->N, p->M, p->logM, twc, p->mode, s));
+        FDR_HIP(launch_transpose(work2, d, p->N, p->M, s));
         return FDR_OK;
     }
     RowArgs ra{};
@@ -184,7 +195,7 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
     // pad top-left + forward 2-D FFT (fft/fft_serial.cpp:166-171,182)
     if (p->simple) {
         FDR_HIP(launch_pad_real_to_complex(d_psf, prows, pcols, pstride, p->filt, p->M, p->N, s));
-        int rc = dft2d_dev(p, p->filt, false, s);
+        int rc = dft2d_dev(p, p->filt, p->work2, false, s);
         if (rc != FDR_OK) return rc;
     } else if (p->panel) {
         RowArgs ra{};
@@ -210,8 +221,8 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
     return FDR_OK;
 }
 
-int wiener_dev_impl(fdr_plan* p, const float* d_img, int rows, int cols, int stride, float* d_out, int out_stride,
-                    int norm_area, hipStream_t s) {
+int wiener_dev_impl(fdr_plan* p, const fdr_plan::Slot& w, const float* d_img, int rows, int cols, int stride, float* d_out,
+                    int out_stride, int norm_area, hipStream_t s) {
     if (!p->have_psf) return fail(FDR_ERR_STATE, "fdr_wiener: no PSF set on this plan (call fdr_set_psf* first)");
     if (!d_img || !d_out) return fail(FDR_ERR_ARG, "fdr_wiener: null image pointer");
     if (rows <= 0 || cols <= 0 || rows > p->M || cols > p->N || stride < cols || out_stride < cols)
@@ -223,37 +234,37 @@ int wiener_dev_impl(fdr_plan* p, const float* d_img, int rows, int cols, int str
 
     if (p->simple) {
         ScopedPass t(p, s, kPassSimple);
-        FDR_HIP(launch_pad_real_to_complex(d_img, rows, cols, stride, p->work, p->M, p->N, s));
-        int rc = dft2d_dev(p, p->work, false, s);
+        FDR_HIP(launch_pad_real_to_complex(d_img, rows, cols, stride, w.work, p->M, p->N, s));
+        int rc = dft2d_dev(p, w.work, w.work2, false, s);
         if (rc != FDR_OK) return rc;
-        FDR_HIP(launch_wiener_pointwise(p->work, p->filt, P, p->K, p->mode, s));
-        rc = dft2d_dev(p, p->work, true, s);
+        FDR_HIP(launch_wiener_pointwise(w.work, p->filt, P, p->K, p->mode, s));
+        rc = dft2d_dev(p, w.work, w.work2, true, s);
         if (rc != FDR_OK) return rc;
-        FDR_HIP(launch_real_minmax(p->work, p->raw, p->M, p->N, mm_rows, mm_cols, p->mm_part, &n_part, s));
+        FDR_HIP(launch_real_minmax(w.work, w.raw, p->M, p->N, mm_rows, mm_cols, w.mm_part, &n_part, s));
     } else if (p->mode == FDR_MODE_PARITY) {
         {   // A: rows, real -> complex (fft/fft_serial.cpp:157-165,176 first half)
             ScopedPass t(p, s, kPassRowsFwd);
             RowArgs a{};
             a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
-            a.dst_c = p->work; a.M = p->M;
+            a.dst_c = w.work; a.M = p->M;
             FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_REAL, ROW_OUT_COMPLEX, false, a, p->tw_row_f, s));
         }
         {   // B: columns forward + Wiener quotient (:176 second half, :186-224)
             ScopedPass t(p, s, kPassColsWiener);
             ColArgs c{};
-            c.data = p->work; c.filt = p->filt; c.K = p->K; c.N = p->N;
+            c.data = w.work; c.filt = p->filt; c.K = p->K; c.N = p->N;
             FDR_HIP(launch_cols(p->logM, p->mode, COL_FWD_WIENER, c, p->tw_col_f, p->tw_col_i, s));
         }
         {   // C: rows inverse (:229 first half)
             ScopedPass t(p, s, kPassRowsInv);
             RowArgs a{};
-            a.src_c = p->work; a.dst_c = p->work; a.M = p->M;
+            a.src_c = w.work; a.dst_c = w.work; a.M = p->M;
             FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, true, a, p->tw_row_i, s));
         }
         {   // D: columns inverse, real plane, min/max (:229 second half, :236-240, minMaxIdx of :246)
             ScopedPass t(p, s, kPassColsInvReal);
             ColArgs c{};
-            c.data = p->work; c.dst_real = p->raw; c.mm_part = p->mm_part; c.mm_rows = mm_rows; c.mm_cols = mm_cols; c.N = p->N;
+            c.data = w.work; c.dst_real = w.raw; c.mm_part = w.mm_part; c.mm_rows = mm_rows; c.mm_cols = mm_cols; c.N = p->N;
             FDR_HIP(launch_cols(p->logM, p->mode, COL_INV_REAL, c, p->tw_col_f, p->tw_col_i, s));
             n_part = cols_minmax_partials(p->logM, p->N);
         }
@@ -262,19 +273,19 @@ int wiener_dev_impl(fdr_plan* p, const float* d_img, int rows, int cols, int str
             ScopedPass t(p, s, kPassRowsFwd);
             RowArgs a{};
             a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
-            a.dst_c = p->work; a.M = p->M; a.no_packing = p->no_packing; a.pstride = p->pstride;
+            a.dst_c = w.work; a.M = p->M; a.no_packing = p->no_packing; a.pstride = p->pstride;
             FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
         }
         {   // B': per panel, columns forward * W * inverse, persistent + register double-buffered
             ScopedPass t(p, s, kPassColsFused);
             ColArgs c{};
-            c.data = p->work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu; c.no_pipeline = p->no_pipeline; c.pstride = p->pstride;
+            c.data = w.work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu; c.no_pipeline = p->no_pipeline; c.pstride = p->pstride;
             FDR_HIP(launch_cols_panel(p->logM, COL_FUSED, c, p->tw_col_f, s));
         }
         {   // C': 4 rows gathered from the panels, inverse, real plane, min/max
             ScopedPass t(p, s, kPassRowsInvReal);
             RowArgs a{};
-            a.src_c = p->work; a.dst_real = p->raw; a.mm_part = p->mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M; a.no_packing = p->no_packing; a.pstride = p->pstride;
+            a.src_c = w.work; a.dst_real = w.raw; a.mm_part = w.mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M; a.no_packing = p->no_packing; a.pstride = p->pstride;
             FDR_HIP(launch_rows4(p->logN, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, a, p->tw_row_f, s));
             n_part = rows4_minmax_partials(p->logN, p->M);
         }
@@ -283,19 +294,19 @@ int wiener_dev_impl(fdr_plan* p, const float* d_img, int rows, int cols, int str
             ScopedPass t(p, s, kPassRowsFwd);
             RowArgs a{};
             a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
-            a.dst_c = p->work; a.M = p->M;
+            a.dst_c = w.work; a.M = p->M;
             FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_REAL, ROW_OUT_COMPLEX, false, a, p->tw_row_f, s));
         }
         {   // B': columns forward, multiply by W, columns inverse -- one HBM round trip
             ScopedPass t(p, s, kPassColsFused);
             ColArgs c{};
-            c.data = p->work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu; c.no_pipeline = p->no_pipeline;
+            c.data = w.work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu; c.no_pipeline = p->no_pipeline;
             FDR_HIP(launch_cols(p->logM, p->mode, COL_FUSED, c, p->tw_col_f, p->tw_col_i, s));
         }
         {   // C': rows inverse, real plane, min/max
             ScopedPass t(p, s, kPassRowsInvReal);
             RowArgs a{};
-            a.src_c = p->work; a.dst_real = p->raw; a.mm_part = p->mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
+            a.src_c = w.work; a.dst_real = w.raw; a.mm_part = w.mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
             FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, true, a, p->tw_row_f, s));
             n_part = rows_minmax_partials(p->logN, p->M);
         }
@@ -304,10 +315,10 @@ int wiener_dev_impl(fdr_plan* p, const float* d_img, int rows, int cols, int str
         ScopedPass t(p, s, kPassNormalize);
         if (n_part <= 0 || n_part > p->mm_part_cap) return fail(FDR_ERR_STATE, "fdr_wiener: min/max partial count out of range");
         if (n_part <= 4096) {
-            FDR_HIP(launch_normalize(p->raw, p->N, p->mm_part, n_part, nullptr, d_out, rows, cols, out_stride, s));
+            FDR_HIP(launch_normalize(w.raw, p->N, w.mm_part, n_part, nullptr, d_out, rows, cols, out_stride, s));
         } else {  // many partials (reference-shaped path): fold them once in a separate launch
-            FDR_HIP(launch_reduce_minmax(p->mm_part, n_part, p->mm, s));
-            FDR_HIP(launch_normalize(p->raw, p->N, nullptr, 0, p->mm, d_out, rows, cols, out_stride, s));
+            FDR_HIP(launch_reduce_minmax(w.mm_part, n_part, w.mm, s));
+            FDR_HIP(launch_normalize(w.raw, p->N, nullptr, 0, w.mm, d_out, rows, cols, out_stride, s));
         }
     }
     return FDR_OK;
@@ -377,6 +388,9 @@ int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan
         rc = fail(FDR_ERR_ALLOC, "fdr_plan_create: hipMalloc of the plan workspace failed");
         goto bad;
     }
+    p->ws_elems = P;
+    p->slots[0].work = p->work; p->slots[0].work2 = p->work2; p->slots[0].raw = p->raw; p->slots[0].mm = p->mm;
+    p->slots[0].mm_part = p->mm_part;
     *out = p;
     return FDR_OK;
 bad:
@@ -388,6 +402,15 @@ int fdr_plan_destroy(fdr_plan* p) {
     if (!p) return FDR_OK;
     (void)hipSetDevice(p->device);
     p->timer.destroy();
+    for (int k = 1; k < fdr_plan::kMaxSlots; ++k) {
+        fdr_plan::Slot& w = p->slots[k];
+        (void)hipFree(w.work); (void)hipFree(w.work2); (void)hipFree(w.raw); (void)hipFree(w.mm); (void)hipFree(w.mm_part);
+    }
+    for (int k = 0; k < fdr_plan::kMaxSlots; ++k) {
+        if (p->slots[k].stream) (void)hipStreamDestroy(p->slots[k].stream);
+        if (p->slots[k].done) (void)hipEventDestroy(p->slots[k].done);
+    }
+    if (p->fork) (void)hipEventDestroy(p->fork);
     (void)hipFree(p->tw_row_f); (void)hipFree(p->tw_row_i); (void)hipFree(p->tw_col_f); (void)hipFree(p->tw_col_i);
     (void)hipFree(p->work); (void)hipFree(p->work2); (void)hipFree(p->filt); (void)hipFree(p->raw);
     (void)hipFree(p->psf_dev); (void)hipFree(p->mm); (void)hipFree(p->mm_part);
@@ -455,7 +478,7 @@ int fdr_wiener_f32_dev(fdr_plan* p, const float* d_img, int rows, int cols, int 
                        int norm_area, void* stream) {
     if (!p) return fail(FDR_ERR_ARG, "fdr_wiener_f32_dev: null plan");
     FDR_HIP(hipSetDevice(p->device));
-    return wiener_dev_impl(p, d_img, rows, cols, stride, d_out, out_stride, norm_area, (hipStream_t)stream);
+    return wiener_dev_impl(p, p->slots[0], d_img, rows, cols, stride, d_out, out_stride, norm_area, (hipStream_t)stream);
 }
 
 int fdr_wiener_batch_f32_dev(fdr_plan* p, const float* d_imgs, size_t img_pitch, int count, int rows, int cols, int stride,
@@ -463,11 +486,53 @@ int fdr_wiener_batch_f32_dev(fdr_plan* p, const float* d_imgs, size_t img_pitch,
     if (!p) return fail(FDR_ERR_ARG, "fdr_wiener_batch_f32_dev: null plan");
     if (count < 0) return fail(FDR_ERR_ARG, "fdr_wiener_batch_f32_dev: negative count");
     FDR_HIP(hipSetDevice(p->device));
+    hipStream_t us = (hipStream_t)stream;
+    // profiling wants clean per-kernel durations: keep everything on the caller's stream then
+    const int ns = (p->timer.enabled || count < 2) ? 1 : p->nslots;
+    if (ns == 1) {
+        for (int i = 0; i < count; ++i) {
+            int rc = wiener_dev_impl(p, p->slots[0], d_imgs + (size_t)i * img_pitch, rows, cols, stride,
+                                     d_out + (size_t)i * out_pitch, out_stride, norm_area, us);
+            if (rc != FDR_OK) return rc;
+        }
+        return FDR_OK;
+    }
+    // fork: internal streams wait for everything queued so far on the caller's stream
+    FDR_HIP(hipEventRecord(p->fork, us));
+    for (int k = 0; k < ns; ++k) FDR_HIP(hipStreamWaitEvent(p->slots[k].stream, p->fork, 0));
     for (int i = 0; i < count; ++i) {
-        int rc = wiener_dev_impl(p, d_imgs + (size_t)i * img_pitch, rows, cols, stride, d_out + (size_t)i * out_pitch,
-                                 out_stride, norm_area, (hipStream_t)stream);
+        const fdr_plan::Slot& w = p->slots[i % ns];
+        int rc = wiener_dev_impl(p, w, d_imgs + (size_t)i * img_pitch, rows, cols, stride, d_out + (size_t)i * out_pitch,
+                                 out_stride, norm_area, w.stream);
         if (rc != FDR_OK) return rc;
     }
+    // join: the caller's stream continues after every internal stream has drained
+    for (int k = 0; k < ns; ++k) {
+        FDR_HIP(hipEventRecord(p->slots[k].done, p->slots[k].stream));
+        FDR_HIP(hipStreamWaitEvent(us, p->slots[k].done, 0));
+    }
+    return FDR_OK;
+}
+
+int fdr_plan_set_concurrency(fdr_plan* p, int nstreams) {
+    if (!p) return fail(FDR_ERR_ARG, "fdr_plan_set_concurrency: null plan");
+    if (nstreams < 1 || nstreams > fdr_plan::kMaxSlots) return fail(FDR_ERR_ARG, "fdr_plan_set_concurrency: 1..4 streams");
+    FDR_HIP(hipSetDevice(p->device));
+    if (!p->fork) FDR_HIP(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
+    for (int k = 0; k < nstreams; ++k) {
+        fdr_plan::Slot& w = p->slots[k];
+        if (!w.stream) FDR_HIP(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+        if (!w.done) FDR_HIP(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+        if (k > 0 && !w.work) {
+            if (hipMalloc((void**)&w.work, p->ws_elems * sizeof(float2)) != hipSuccess ||
+                hipMalloc((void**)&w.raw, p->ws_elems * sizeof(float)) != hipSuccess ||
+                hipMalloc((void**)&w.mm, 2 * sizeof(float)) != hipSuccess ||
+                hipMalloc((void**)&w.mm_part, (size_t)p->mm_part_cap * sizeof(float2)) != hipSuccess ||
+                (p->simple && hipMalloc((void**)&w.work2, p->ws_elems * sizeof(float2)) != hipSuccess))
+                return fail(FDR_ERR_ALLOC, "fdr_plan_set_concurrency: hipMalloc of an extra workspace failed");
+        }
+    }
+    p->nslots = nstreams;
     return FDR_OK;
 }
 
@@ -484,7 +549,7 @@ int fdr_wiener_f32(fdr_plan* p, const float* img_host, int rows, int cols, int s
     hipError_t e = hipMemcpy2D(d_in, (size_t)cols * sizeof(float), img_host, (size_t)stride * sizeof(float),
                                (size_t)cols * sizeof(float), rows, hipMemcpyHostToDevice);
     int rc = FDR_OK;
-    if (e == hipSuccess) rc = wiener_dev_impl(p, d_in, rows, cols, cols, d_out, cols, norm_area, nullptr);
+    if (e == hipSuccess) rc = wiener_dev_impl(p, p->slots[0], d_in, rows, cols, cols, d_out, cols, norm_area, nullptr);
     if (e == hipSuccess && rc == FDR_OK)
         e = hipMemcpy2D(out_host, (size_t)out_stride * sizeof(float), d_out, (size_t)cols * sizeof(float),
                         (size_t)cols * sizeof(float), rows, hipMemcpyDeviceToHost);
@@ -497,7 +562,7 @@ int fdr_wiener_f32(fdr_plan* p, const float* img_host, int rows, int cols, int s
 int fdr_fft2d_c2c_dev(fdr_plan* p, float* d_data, int inverse, void* stream) {
     if (!p || !d_data) return fail(FDR_ERR_ARG, "fdr_fft2d_c2c_dev: null argument");
     FDR_HIP(hipSetDevice(p->device));
-    return dft2d_dev(p, reinterpret_cast<float2*>(d_data), inverse != 0, (hipStream_t)stream);
+    return dft2d_dev(p, reinterpret_cast<float2*>(d_data), p->work2, inverse != 0, (hipStream_t)stream);
 }
 
 int fdr_fft2d_c2c(fdr_plan* p, float* data_host, int inverse) {
@@ -506,7 +571,7 @@ int fdr_fft2d_c2c(fdr_plan* p, float* data_host, int inverse) {
     const size_t bytes = (size_t)p->M * p->N * sizeof(float2);
     // p->work is free between operator calls; use it as the staging buffer
     FDR_HIP(hipMemcpy(p->work, data_host, bytes, hipMemcpyHostToDevice));
-    int rc = dft2d_dev(p, p->work, inverse != 0, nullptr);
+    int rc = dft2d_dev(p, p->work, p->work2, inverse != 0, nullptr);
     if (rc != FDR_OK) return rc;
     FDR_HIP(hipMemcpy(data_host, p->work, bytes, hipMemcpyDeviceToHost));
     return FDR_OK;
