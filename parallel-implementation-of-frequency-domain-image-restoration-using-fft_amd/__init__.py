@@ -53,6 +53,15 @@ def _load():
         raise ImportError(
             "libfdr.so not found at %s: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; g.build()'`). "
             "There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64 and publishes
+    # them in the global symbol scope.  Loaded first, libfdr.so binds to that same runtime, so device
+    # pointers and hipStream_t handles can be shared with torch; loaded second, torch's runtime would
+    # find the GPU already claimed ("No HIP GPUs are available").  Without torch (C++ callers, the CLI)
+    # libfdr.so simply uses /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for this binding
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, ci, cf, cd, cu = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_uint
     L.fdr_version.restype = ci

@@ -155,3 +155,136 @@ def test_errors(fdr):
         p.set_psf(np.ones((3, 3), np.float32) / 9)
         with pytest.raises(fdr.FdrError):
             p.wiener(np.zeros((65, 64), np.float32))  # image larger than the plan
+
+
+# ------------------------------------------------------------------------------------------------
+# committed vectors (tests/golden/oracle_vectors.npz, generated by tests/golden/make_golden.py)
+# ------------------------------------------------------------------------------------------------
+import os as _os
+
+_GOLD = np.load(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "oracle_vectors.npz"))
+
+
+def test_committed_vectors_on_gpu(fdr):
+    for n in (2, 4, 8, 16, 64, 1024):
+        x = _GOLD["fft1d_in_%d" % n]
+        _assert_same(fdr.fft1d(x, False, fdr.MODE_PARITY), _GOLD["fft1d_fwd_%d" % n], "golden fft1d fwd %d" % n)
+        _assert_same(fdr.fft1d(x, True, fdr.MODE_PARITY), _GOLD["fft1d_inv_%d" % n], "golden fft1d inv %d" % n)
+    for key, shape in (("8x8", (8, 8)), ("32x64", (32, 64))):
+        with fdr.Plan(shape[0], shape[1], fdr.MODE_PARITY) as p:
+            _assert_same(p.fft2d(_GOLD["fft2d_in_" + key], False), _GOLD["fft2d_fwd_" + key], "golden fft2d fwd " + key)
+            _assert_same(p.fft2d(_GOLD["fft2d_in_" + key], True), _GOLD["fft2d_inv_" + key], "golden fft2d inv " + key)
+    for size, ang in ((50, 30.0), (40, 45.0), (15, 10.0)):
+        _assert_same(fdr.motionBlurKernel(size, ang), _GOLD["psf_%d_%d" % (size, int(ang))], "golden psf")
+    psf = _GOLD["psf_15_10"] * 0 + fdr.motionBlurKernel(15, 30.0)
+    from oracle import oracle as o
+    for shape in ((64, 64), (100, 200)):
+        img = o.synth_image(0x5EED0002, 0, shape[0] * shape[1]).reshape(shape)
+        got = fdr.wienerDeblur_myfft(img, psf, 0.01, mode=fdr.MODE_PARITY)
+        _assert_same(got, _GOLD["wiener_serial_%dx%d" % shape], "golden wiener %s" % (shape,))
+
+
+# ------------------------------------------------------------------------------------------------
+# fast-mode variants, batched mode, large sizes
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("flags_name", ["FLAG_ROWMAJOR", "FLAG_NO_PACKING", "FLAG_NO_PIPELINE", "FLAG_POW2_PANELS", "FLAG_SIMPLE_PATH"])
+@pytest.mark.parametrize("shape", [(200, 300), (1024, 1024)])
+def test_fast_variants_within_tolerance(fdr, oracle, flags_name, shape):
+    psf = oracle.motion_blur_kernel(50, 30.0)
+    img = _image(oracle, shape[0], shape[1], 0x5EED0002)
+    ref = oracle.serial_channel(img, psf, 0.01)
+    with fdr.Plan(fdr.nextPowerOfTwo(shape[0]), fdr.nextPowerOfTwo(shape[1]), fdr.MODE_FAST, flags=getattr(fdr, flags_name)) as p:
+        p.set_psf(psf, 0.01)
+        got = p.wiener(img)
+    assert np.abs(got - ref).max() <= TOL and np.linalg.norm(got - ref) / np.linalg.norm(ref) <= TOL
+
+
+def test_psf_generated_on_device_into_the_plan(fdr, oracle):
+    psf = oracle.motion_blur_kernel(50, 30.0)
+    img = _image(oracle, 256, 256, 5)
+    with fdr.Plan(256, 256, fdr.MODE_PARITY) as p, fdr.Plan(256, 256, fdr.MODE_PARITY) as q:
+        p.set_psf(psf, 0.01)
+        q.set_psf_motion(50, 30.0, 0.01)
+        _assert_same(p.wiener(img), q.wiener(img), "set_psf vs set_psf_motion")
+
+
+@pytest.mark.parametrize("mode_name", ["MODE_PARITY", "MODE_FAST"])
+def test_batched_multistream_equals_one_by_one(fdr, oracle, mode_name):
+    import torch
+    mode = getattr(fdr, mode_name)
+    rows, cols, B = 100, 200, 5
+    psf = oracle.motion_blur_kernel(15, 30.0)
+    host = np.stack([_image(oracle, rows, cols, 100 + i) for i in range(B)])
+    d_in = torch.from_numpy(host).cuda()
+    d_out1 = torch.zeros_like(d_in)
+    d_out3 = torch.zeros_like(d_in)
+    s = torch.cuda.current_stream().cuda_stream
+    with fdr.Plan(128, 256, mode) as p:
+        p.set_psf(psf, 0.01)
+        p.wiener_batch_dev(d_in.data_ptr(), rows * cols, B, rows, cols, cols, d_out1.data_ptr(), rows * cols, cols, stream=s)
+        p.set_concurrency(3)
+        p.wiener_batch_dev(d_in.data_ptr(), rows * cols, B, rows, cols, cols, d_out3.data_ptr(), rows * cols, cols, stream=s)
+        torch.cuda.synchronize()
+        one = np.stack([p.wiener(host[i]) for i in range(B)])
+    _assert_same(d_out1.cpu().numpy(), one, "batched (1 stream) vs one by one")
+    _assert_same(d_out3.cpu().numpy(), one, "batched (3 streams) vs one by one")
+    if mode == fdr.MODE_PARITY:
+        _assert_same(one[2], oracle.serial_channel(host[2], psf, 0.01), "batched vs oracle")
+
+
+def test_synth_generator_matches_oracle_bits(fdr, oracle):
+    import torch
+    d = torch.empty(5000, dtype=torch.float32, device="cuda")
+    fdr.synth_image_dev(d.data_ptr(), 5000, 0x5EED0003, first_index=123)
+    torch.cuda.synchronize()
+    _assert_same(d.cpu().numpy(), oracle.synth_image(0x5EED0003, 123, 5000), "synthetic image generator")
+
+
+@pytest.mark.parametrize("mode_name", ["MODE_PARITY", "MODE_FAST"])
+def test_2048_against_oracle(fdr, oracle, mode_name):
+    psf = oracle.motion_blur_kernel(50, 30.0)
+    img = _image(oracle, 2048, 2048, 0x5EED0005)
+    ref = oracle.serial_channel(img, psf, 0.01)
+    got = fdr.wienerDeblur_myfft(img, psf, 0.01, mode=getattr(fdr, mode_name))
+    if mode_name == "MODE_PARITY":
+        _assert_same(got, ref, "2048^2 parity")
+    else:
+        assert np.abs(got - ref).max() <= TOL
+
+
+@pytest.mark.parametrize("S", [4096, 8192])
+def test_full_size_properties(fdr, S):
+    """BASELINE sizes, where the oracle is too slow for a unit test: size-independent properties.
+    (a) inverse(forward(x)) = M N x (both transforms unscaled, fft_serial.cpp:67), (b) Parseval,
+    (c) the restored plane spans exactly [0, 1], (d) fast and parity modes agree within 1e-4,
+    (e) a non-power-of-two input is padded, normalised over the padded area and cropped."""
+    import torch
+    mode_fft = fdr.MODE_FAST
+    g = torch.Generator(device="cuda").manual_seed(S)
+    x = torch.rand((S, S, 2), generator=g, device="cuda", dtype=torch.float32) - 0.5
+    y = x.clone()
+    with fdr.Plan(S, S, mode_fft) as p:
+        p.fft2d_dev(y.data_ptr(), False)
+        torch.cuda.synchronize()
+        e_in = float((x.double() ** 2).sum()); e_out = float((y.double() ** 2).sum())
+        assert abs(e_out / (e_in * S * S) - 1.0) < 1e-5
+        p.fft2d_dev(y.data_ptr(), True)
+        torch.cuda.synchronize()
+        err = float(((y / float(S * S) - x).abs()).max())
+        assert err < 2e-5, err
+    del x, y
+    rows, cols = (S, S) if S == 4096 else (8000, 8100)  # config 4: non power of two -> 8192^2 pad check
+    from oracle import oracle as o
+    img_h = o.synth_image(0x5EED0003 if S == 4096 else 0x5EED0004, 0, rows * cols).reshape(rows, cols)
+    psf = o.motion_blur_kernel(50, 30.0)
+    outs = {}
+    for name in ("MODE_FAST", "MODE_PARITY"):
+        with fdr.Plan(S, S, getattr(fdr, name)) as p:
+            p.set_psf(psf, 0.01)
+            outs[name] = p.wiener(img_h)
+    f, q = outs["MODE_FAST"], outs["MODE_PARITY"]
+    assert f.shape == (rows, cols)
+    assert np.abs(f - q).max() <= TOL, np.abs(f - q).max()
+    assert q.min() >= 0.0 and q.max() <= 1.0 and f.min() >= 0.0 and f.max() <= 1.0
+    if (rows, cols) == (S, S):
+        assert q.min() == 0.0 and abs(float(q.max()) - 1.0) < 1e-6  # max*scale+shift rounds to 1 - 1ulp at most
