@@ -59,18 +59,26 @@ def parse():
 
 
 def cpu_baseline(size):
-    """Oracle (kind 'port'), one thread, one size x size single-channel image."""
+    """Oracle (kind 'port'), one thread: as many size x size single-channel images as fit ~12 s."""
     from oracle import oracle as o
     o.build()
     psf = o.motion_blur_kernel(50, 30.0)
-    img = o.synth_image(SEEDS.get(size, 0x5EED0000), 0, size * size).reshape(size, size)
+    P = size * size
+    img = o.synth_image(SEEDS.get(size, 0x5EED0000), 0, P).reshape(size, size)
     t0 = time.perf_counter()
     o.serial_channel(img, psf, 0.01)
-    dt = time.perf_counter() - t0
+    first = time.perf_counter() - t0
+    extra = max(0, min(7, int(12.0 / first) - 1))
+    more = [o.synth_image(SEEDS.get(size, 0x5EED0000), (b + 1) * P, P).reshape(size, size) for b in range(extra)]
+    t0 = time.perf_counter()
+    for im in more:
+        o.serial_channel(im, psf, 0.01)
+    dt = first + (time.perf_counter() - t0 if extra else 0.0)
+    n = 1 + extra
     return {
-        "value": round(size * size / 1e6 / dt, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-        "sample": "1 image %dx%d fp32, PSF 50/30deg, K=0.01, oracle/fdr_oracle.c (gcc -O2, no FMA), %.2f s on 1 of %d host cores"
-                  % (size, size, dt, os.cpu_count() or 0),
+        "value": round(n * P / 1e6 / dt, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+        "sample": "%d image(s) %dx%d fp32, PSF 50/30deg, K=0.01, oracle/fdr_oracle.c (gcc -O2, no FMA), %.1f s on 1 of %d host cores"
+                  % (n, size, size, dt, os.cpu_count() or 0),
     }
 
 
