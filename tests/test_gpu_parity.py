@@ -288,3 +288,33 @@ def test_full_size_properties(fdr, S):
     assert q.min() >= 0.0 and q.max() <= 1.0 and f.min() >= 0.0 and f.max() <= 1.0
     if (rows, cols) == (S, S):
         assert q.min() == 0.0 and abs(float(q.max()) - 1.0) < 1e-6  # max*scale+shift rounds to 1 - 1ulp at most
+
+
+def test_drop_in_cli(fdr, tmp_path):
+    """tools/cli/gpu (C++ over the C ABI: include/fft/fft.hpp + include/utils.hpp) on the reference's
+    own input picture: same restored planes as the Python binding of the same library, and the
+    printed lines of the reference driver (gpu.cpp:104-113)."""
+    import subprocess
+    from PIL import Image
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", _os.path.join(root, "tools", "cli"), "-s"])
+    png = _os.path.join(root, "tests", "golden", "car_blurred.png")
+    out_png, out_raw = str(tmp_path / "car.png"), str(tmp_path / "car.f32")
+    r = subprocess.run([_os.path.join(root, "tools", "cli", "gpu"), png, "40", "45", "--mode", "parity", "--out", out_png,
+                        "--raw-out", out_raw], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Deblurring 3 channels took(gpu[optimize]):" in r.stdout and "Deblurring 3 channels took(gpu):" in r.stdout
+    assert "[Speedup]" in r.stdout and "=== FAST (Reuse Memory) Profiling (3 Channels) ===" in r.stdout
+    rgb = np.asarray(Image.open(png).convert("RGB"), dtype=np.float32) / 255.0  # (330, 640, 3)
+    h, w = rgb.shape[:2]
+    planes = np.fromfile(out_raw, dtype=np.float32).reshape(3, h, w)  # B, G, R
+    psf = fdr.motionBlurKernel(40, 45.0)
+    for k, ch in enumerate((2, 1, 0)):
+        want = fdr.wienerDeblur_myfft(np.ascontiguousarray(rgb[:, :, ch]), psf, 0.01, mode=fdr.MODE_PARITY)
+        _assert_same(planes[k], want, "CLI plane %d" % k)
+    res = np.asarray(Image.open(out_png))
+    assert res.shape == (h, w, 3) and res.dtype == np.uint8 and 20 < res.mean() < 235
+    # usage / unreadable image behave as the reference driver (return -1 -> exit status 255)
+    assert subprocess.run([_os.path.join(root, "tools", "cli", "gpu")], capture_output=True).returncode == 255
+    bad = subprocess.run([_os.path.join(root, "tools", "cli", "gpu"), "/nonexistent.png", "40", "45"], capture_output=True, text=True)
+    assert bad.returncode == 255 and "Cannot read image" in bad.stdout
