@@ -54,6 +54,9 @@ extern "C" {
 
 #define FDR_FLAG_POW2_PANELS 16u /* fast mode: panel stride exactly 4*M elements (no channel skew; A/B) */
 
+#define FDR_FLAG_FULL_SPECTRUM 32u /* fast mode: keep all N columns of the (Hermitian) spectrum instead of
+                                      N/2 + 1 (A/B measurements; implied by NO_PACKING and ROWMAJOR)     */
+
 /* normalisation area selector for fdr_wiener_* */
 #define FDR_NORM_PADDED 1  /* serial semantics: min/max over the padded M x N area, then crop
                               (serial.cpp:36-38 + fft/fft_serial.cpp:243-246)                 */

@@ -25,6 +25,7 @@ FLAG_NO_PIPELINE = 2
 FLAG_ROWMAJOR = 4
 FLAG_NO_PACKING = 8
 FLAG_POW2_PANELS = 16
+FLAG_FULL_SPECTRUM = 32
 NORM_PADDED = 1
 NORM_CROPPED = 0
 MAX_PASSES = 8

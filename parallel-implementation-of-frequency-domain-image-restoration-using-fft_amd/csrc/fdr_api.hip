@@ -108,7 +108,9 @@ struct fdr_plan {
     int no_pipeline = 0;
     int no_packing = 0;
     bool panel = false;
-    size_t pstride = 0;  // panel stride (float2 elements)  // fast mode: panel-major intermediate spectrum and filter
+    size_t pstride = 0;  // panel stride (float2 elements)
+    bool half = false;   // fast mode: only the non-redundant half of the Hermitian spectrum is kept (N/8 + 1 panels)
+    int npanels = 0;  // fast mode: panel-major intermediate spectrum and filter
     float2 *tw_row_f = nullptr, *tw_row_i = nullptr, *tw_col_f = nullptr, *tw_col_i = nullptr;
     float2* work = nullptr;   // M x N complex working spectrum
     float2* work2 = nullptr;  // simple path: N x M transpose buffer
@@ -200,10 +202,10 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
     } else if (p->panel) {
         RowArgs ra{};
         ra.src_real = d_psf; ra.src_rows = prows; ra.src_cols = pcols; ra.src_stride = pstride;
-        ra.dst_c = p->filt; ra.M = p->M; ra.no_packing = p->no_packing; ra.pstride = p->pstride;
+        ra.dst_c = p->filt; ra.M = p->M; ra.no_packing = p->no_packing; ra.pstride = p->pstride; ra.half = p->half;
         FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, ra, p->tw_row_f, s));
         ColArgs ca{};
-        ca.data = p->filt; ca.N = p->N; ca.num_cu = p->num_cu; ca.pstride = p->pstride;
+        ca.data = p->filt; ca.N = p->N; ca.num_cu = p->num_cu; ca.pstride = p->pstride; ca.npanels = p->npanels;
         FDR_HIP(launch_cols_panel(p->logM, COL_FWD, ca, p->tw_col_f, s));
     } else {
         RowArgs ra{};
@@ -215,7 +217,7 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
         FDR_HIP(launch_cols(p->logM, p->mode, COL_FWD, ca, p->tw_col_f, p->tw_col_i, s));
     }
     if (p->mode == FDR_MODE_FAST)
-        FDR_HIP(launch_make_filter_fast(p->filt, p->filt, p->panel ? (size_t)(p->N / 4) * p->pstride : (size_t)p->M * p->N, K, s));
+        FDR_HIP(launch_make_filter_fast(p->filt, p->filt, p->panel ? (size_t)p->npanels * p->pstride : (size_t)p->M * p->N, K, s));
     p->K = K;
     p->have_psf = true;
     return FDR_OK;
@@ -273,19 +275,19 @@ int wiener_dev_impl(fdr_plan* p, const fdr_plan::Slot& w, const float* d_img, in
             ScopedPass t(p, s, kPassRowsFwd);
             RowArgs a{};
             a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
-            a.dst_c = w.work; a.M = p->M; a.no_packing = p->no_packing; a.pstride = p->pstride;
+            a.dst_c = w.work; a.M = p->M; a.no_packing = p->no_packing; a.pstride = p->pstride; a.half = p->half;
             FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
         }
         {   // B': per panel, columns forward * W * inverse, persistent + register double-buffered
             ScopedPass t(p, s, kPassColsFused);
             ColArgs c{};
-            c.data = w.work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu; c.no_pipeline = p->no_pipeline; c.pstride = p->pstride;
+            c.data = w.work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu; c.no_pipeline = p->no_pipeline; c.pstride = p->pstride; c.npanels = p->npanels;
             FDR_HIP(launch_cols_panel(p->logM, COL_FUSED, c, p->tw_col_f, s));
         }
         {   // C': 4 rows gathered from the panels, inverse, real plane, min/max
             ScopedPass t(p, s, kPassRowsInvReal);
             RowArgs a{};
-            a.src_c = w.work; a.dst_real = w.raw; a.mm_part = w.mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M; a.no_packing = p->no_packing; a.pstride = p->pstride;
+            a.src_c = w.work; a.dst_real = w.raw; a.mm_part = w.mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M; a.no_packing = p->no_packing; a.pstride = p->pstride; a.half = p->half;
             FDR_HIP(launch_rows4(p->logN, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, a, p->tw_row_f, s));
             n_part = rows4_minmax_partials(p->logN, p->M);
         }
@@ -371,7 +373,9 @@ int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan
     size_t P = (size_t)M * N;
     if (p->panel) {  // panel-major buffers: N/4 panels of PS elements
         p->pstride = (size_t)M * 4 + ((flags & FDR_FLAG_POW2_PANELS) ? 0 : 16);
-        P = (size_t)(N / 4) * p->pstride;
+        p->half = !p->no_packing && N >= 32 && (flags & FDR_FLAG_FULL_SPECTRUM) == 0;
+        p->npanels = p->half ? N / 8 + 1 : N / 4;
+        P = (size_t)p->npanels * p->pstride;
     }
     std::vector<float2> t;
     int rc = FDR_OK;
@@ -381,7 +385,7 @@ int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan
     build_twiddles(M, mode, true, t);  if ((rc = upload(&p->tw_col_i, t)) != FDR_OK) goto bad;
     if (hipMalloc((void**)&p->work, P * sizeof(float2)) != hipSuccess ||
         hipMalloc((void**)&p->filt, P * sizeof(float2)) != hipSuccess ||
-        hipMalloc((void**)&p->raw, P * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&p->raw, (size_t)M * N * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&p->mm, 2 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&p->mm_part, (size_t)(p->mm_part_cap = (int)(((size_t)N + 255) / 256 * M + 8192)) * sizeof(float2)) != hipSuccess ||
         (p->simple && hipMalloc((void**)&p->work2, P * sizeof(float2)) != hipSuccess)) {
@@ -525,7 +529,7 @@ int fdr_plan_set_concurrency(fdr_plan* p, int nstreams) {
         if (!w.done) FDR_HIP(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
         if (k > 0 && !w.work) {
             if (hipMalloc((void**)&w.work, p->ws_elems * sizeof(float2)) != hipSuccess ||
-                hipMalloc((void**)&w.raw, p->ws_elems * sizeof(float)) != hipSuccess ||
+                hipMalloc((void**)&w.raw, (size_t)p->M * p->N * sizeof(float)) != hipSuccess ||
                 hipMalloc((void**)&w.mm, 2 * sizeof(float)) != hipSuccess ||
                 hipMalloc((void**)&w.mm_part, (size_t)p->mm_part_cap * sizeof(float2)) != hipSuccess ||
                 (p->simple && hipMalloc((void**)&w.work2, p->ws_elems * sizeof(float2)) != hipSuccess))

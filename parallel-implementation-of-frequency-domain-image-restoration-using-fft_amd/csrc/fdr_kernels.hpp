@@ -29,6 +29,7 @@ struct RowArgs {
     int mm_rows, mm_cols;
     int M;              // number of rows to transform
     size_t pstride;     // rows4 kernels: panel stride of the panel-major spectrum, in float2 elements
+    int half;           // rows4 packed kernels: half (Hermitian) spectrum, N/8 + 1 panels
     int no_packing;     // rows4 kernels: one complex transform per row instead of two rows per transform
 };
 
@@ -40,6 +41,7 @@ struct ColArgs {
     float2* mm_part;  // one (min, max) partial per workgroup
     int mm_rows, mm_cols;
     int N;  // row length (number of columns)
+    int npanels;      // panel kernels: number of panels (0 = N/4)
     size_t pstride;   // panel kernels: panel stride in float2 elements
     int num_cu;       // CUs of the device (persistent pass B' launches one workgroup per CU)
     int no_pipeline;  // debug/bench: use the non-persistent fused kernel

@@ -131,7 +131,9 @@ struct Rows4PackGeom {
     static constexpr int THREADS = T * G;
 };
 
-template <int LOGL>
+// HALF: keep only the non-redundant half of each Hermitian row spectrum -- columns 0 .. N/2-1 in panels
+// 0 .. N/8-1 plus the (real) Nyquist column N/2 as column 0 of one extra panel N/8 (columns 1..3 zero).
+template <int LOGL, bool HALF>
 __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_packed_kernel(const RowArgs a,
                                                                                           const float2* __restrict__ tw_fwd) {
     using St = Steps<LOGL>;
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
         const float2* buf = grp_lds + ((SEQ1 + (j >> 1)) & 1) * St::BUF;  // packed pair holding row j
         const bool odd = (j & 1) != 0;                            // row b of the pair (else row a)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < (HALF ? 4 : 8); ++i) {
             const int c = (tid >> 2) + (T / 4) * i;  // panel
             const int n0 = c * 4;
             float2 o[4];
@@ -219,6 +221,11 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
                            : make_float2(0.5f * (zn.x + zm.x), 0.5f * (zn.y - zm.y));
             }
             if (active) store4(a.dst_c + (size_t)c * a.pstride + (size_t)(r0 + j) * 4, o[0], o[1], o[2], o[3]);
+        }
+        if (HALF && (tid >> 2) == 0 && active) {  // Nyquist column: X_a[N/2] = Re Z[N/2], X_b[N/2] = Im Z[N/2]
+            const float2 zq = buf[L / 2];
+            const float2 z0 = make_float2(0.f, 0.f);
+            store4(a.dst_c + (size_t)(L / 8) * a.pstride + (size_t)(r0 + j) * 4, make_float2(odd ? zq.y : zq.x, 0.f), z0, z0, z0);
         }
     } else {
 #pragma unroll
@@ -249,7 +256,9 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
     }
 }
 
-template <int LOGL>
+// HALF: the row spectra hold columns 0 .. N/2 only (see the forward kernel); the upper half is rebuilt on
+// load as the conjugate of the mirrored column (every stored line is touched twice by the same workgroup).
+template <int LOGL, bool HALF>
 __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_packed_kernel(const RowArgs a,
                                                                                           const float2* __restrict__ tw_fwd) {
     using St = Steps<LOGL>;
@@ -273,8 +282,17 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_pa
         for (int q = 0; q < Core::RHO0; ++q) {
             const int s = u * Core::RHO0 + q;
             const int n = Core::in_index(tid, u, q);
-            const float2* p = a.src_c + (size_t)(n >> 2) * a.pstride + (size_t)rr * 4 + (n & 3);
-            const float2 y0 = p[0], y1 = p[4], y2 = p[8], y3 = p[12];
+            int pidx = n >> 2, cidx = n & 3;
+            float sgn = 1.0f;
+            if (HALF) {
+                const int m = n <= L / 2 ? n : L - n;  // stored column
+                sgn = n > L / 2 ? -1.0f : 1.0f;        // conjugate for the mirrored half
+                pidx = m == L / 2 ? L / 8 : (m >> 2);
+                cidx = m == L / 2 ? 0 : (m & 3);
+            }
+            const float2* p = a.src_c + (size_t)pidx * a.pstride + (size_t)rr * 4 + cidx;
+            float2 y0 = p[0], y1 = p[4], y2 = p[8], y3 = p[12];
+            y0.y *= sgn; y1.y *= sgn; y2.y *= sgn; y3.y *= sgn;
             z[0][s] = make_float2(y0.x - y1.y, y0.y + y1.x);  // Y_a + i Y_b
             z[1][s] = make_float2(y2.x - y3.y, y2.y + y3.x);
         }
@@ -311,10 +329,12 @@ static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const f
     static_assert(Rows4PackGeom<LOGL>::G == Geo::G && Rows4PackGeom<LOGL>::THREADS == Geo::THREADS, "same launch shape");
     if (in == ROW_IN_REAL && out == ROW_OUT_COMPLEX) {
         if (a.no_packing) hipLaunchKernelGGL((fft_rows4_kernel<LOGL, ROW_IN_REAL, ROW_OUT_COMPLEX, false>), grid, block, 0, s, a, tw);
-        else hipLaunchKernelGGL((fft_rows4_fwd_packed_kernel<LOGL>), grid, block, 0, s, a, tw);
+        else if (a.half) hipLaunchKernelGGL((fft_rows4_fwd_packed_kernel<LOGL, true>), grid, block, 0, s, a, tw);
+        else hipLaunchKernelGGL((fft_rows4_fwd_packed_kernel<LOGL, false>), grid, block, 0, s, a, tw);
     } else if (in == ROW_IN_COMPLEX && out == ROW_OUT_REAL_MINMAX) {
         if (a.no_packing) hipLaunchKernelGGL((fft_rows4_kernel<LOGL, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, true>), grid, block, 0, s, a, tw);
-        else hipLaunchKernelGGL((fft_rows4_inv_packed_kernel<LOGL>), grid, block, 0, s, a, tw);
+        else if (a.half) hipLaunchKernelGGL((fft_rows4_inv_packed_kernel<LOGL, true>), grid, block, 0, s, a, tw);
+        else hipLaunchKernelGGL((fft_rows4_inv_packed_kernel<LOGL, false>), grid, block, 0, s, a, tw);
     } else {
         return hipErrorInvalidValue;
     }
@@ -518,7 +538,7 @@ template <int LOGM>
 static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const float2* tw, hipStream_t s) {
     using Geo = PanelGeom<LOGM>;
     const size_t ps = a.pstride;
-    const int npanels = a.N / 4;
+    const int npanels = a.npanels > 0 ? a.npanels : a.N / 4;  // half spectrum: N/8 + 1
     const int ntiles = (npanels + Geo::G - 1) / Geo::G;
     if (kind == COL_FWD) {
         hipLaunchKernelGGL((fft_cols_panel_fwd_kernel<LOGM>), dim3(ntiles), dim3(Geo::THREADS), 0, s, a.data, tw, ps, npanels);
