@@ -109,7 +109,7 @@ struct fdr_plan {
     int no_packing = 0;
     bool panel = false;
     size_t pstride = 0;  // panel stride (float2 elements)
-    bool half = false;   // fast mode: only the non-redundant half of the Hermitian spectrum is kept (N/8 + 1 panels)
+    bool half = false;   // fast mode: only the non-redundant half of the Hermitian spectrum is kept (N/8 panels, Nyquist packed into column 0)
     int npanels = 0;  // fast mode: panel-major intermediate spectrum and filter
     float2 *tw_row_f = nullptr, *tw_row_i = nullptr, *tw_col_f = nullptr, *tw_col_i = nullptr;
     float2* work = nullptr;   // M x N complex working spectrum
@@ -216,8 +216,12 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
         ca.data = p->filt; ca.N = p->N;
         FDR_HIP(launch_cols(p->logM, p->mode, COL_FWD, ca, p->tw_col_f, p->tw_col_i, s));
     }
+    if (p->mode == FDR_MODE_FAST && p->half)  // packed DC/Nyquist column: its slot values need H at k and M-k
+        FDR_HIP(launch_filter_packed_column(p->filt, p->M, K, reinterpret_cast<float2*>(p->raw), s));
     if (p->mode == FDR_MODE_FAST)
         FDR_HIP(launch_make_filter_fast(p->filt, p->filt, p->panel ? (size_t)p->npanels * p->pstride : (size_t)p->M * p->N, K, s));
+    if (p->mode == FDR_MODE_FAST && p->half)
+        FDR_HIP(launch_scatter_column(reinterpret_cast<const float2*>(p->raw), p->M, p->filt, s));
     p->K = K;
     p->have_psf = true;
     return FDR_OK;
@@ -281,7 +285,7 @@ int wiener_dev_impl(fdr_plan* p, const fdr_plan::Slot& w, const float* d_img, in
         {   // B': per panel, columns forward * W * inverse, persistent + register double-buffered
             ScopedPass t(p, s, kPassColsFused);
             ColArgs c{};
-            c.data = w.work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu; c.no_pipeline = p->no_pipeline; c.pstride = p->pstride; c.npanels = p->npanels;
+            c.data = w.work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu; c.no_pipeline = p->no_pipeline; c.pstride = p->pstride; c.npanels = p->npanels; c.packed0 = p->half ? 1 : 0;
             FDR_HIP(launch_cols_panel(p->logM, COL_FUSED, c, p->tw_col_f, s));
         }
         {   // C': 4 rows gathered from the panels, inverse, real plane, min/max
@@ -374,7 +378,7 @@ int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan
     if (p->panel) {  // panel-major buffers: N/4 panels of PS elements
         p->pstride = (size_t)M * 4 + ((flags & FDR_FLAG_POW2_PANELS) ? 0 : 16);
         p->half = !p->no_packing && N >= 32 && (flags & FDR_FLAG_FULL_SPECTRUM) == 0;
-        p->npanels = p->half ? N / 8 + 1 : N / 4;
+        p->npanels = p->half ? N / 8 : N / 4;
         P = (size_t)p->npanels * p->pstride;
     }
     std::vector<float2> t;

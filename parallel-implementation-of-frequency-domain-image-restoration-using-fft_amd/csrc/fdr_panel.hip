@@ -132,7 +132,8 @@ struct Rows4PackGeom {
 };
 
 // HALF: keep only the non-redundant half of each Hermitian row spectrum -- columns 0 .. N/2-1 in panels
-// 0 .. N/8-1 plus the (real) Nyquist column N/2 as column 0 of one extra panel N/8 (columns 1..3 zero).
+// 0 .. N/8-1.  X[m,0] and X[m,N/2] are real for a real row, so the Nyquist column rides in the imaginary
+// part of column 0: stored(m, 0) = X[m,0] + i X[m,N/2]  ("packed column", undone in passes B' and C').
 template <int LOGL, bool HALF>
 __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_packed_kernel(const RowArgs a,
                                                                                           const float2* __restrict__ tw_fwd) {
@@ -220,12 +221,11 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
                 o[k] = odd ? make_float2(0.5f * (zn.y + zm.y), 0.5f * (zm.x - zn.x))
                            : make_float2(0.5f * (zn.x + zm.x), 0.5f * (zn.y - zm.y));
             }
+            if (HALF && n0 == 0) {  // packed column: (X[0], X[N/2]), both real: Re/Im of Z[0] and Z[N/2]
+                const float2 z0 = buf[0], zq = buf[L / 2];
+                o[0] = odd ? make_float2(z0.y, zq.y) : make_float2(z0.x, zq.x);
+            }
             if (active) store4(a.dst_c + (size_t)c * a.pstride + (size_t)(r0 + j) * 4, o[0], o[1], o[2], o[3]);
-        }
-        if (HALF && (tid >> 2) == 0 && active) {  // Nyquist column: X_a[N/2] = Re Z[N/2], X_b[N/2] = Im Z[N/2]
-            const float2 zq = buf[L / 2];
-            const float2 z0 = make_float2(0.f, 0.f);
-            store4(a.dst_c + (size_t)(L / 8) * a.pstride + (size_t)(r0 + j) * 4, make_float2(odd ? zq.y : zq.x, 0.f), z0, z0, z0);
         }
     } else {
 #pragma unroll
@@ -256,8 +256,9 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
     }
 }
 
-// HALF: the row spectra hold columns 0 .. N/2 only (see the forward kernel); the upper half is rebuilt on
-// load as the conjugate of the mirrored column (every stored line is touched twice by the same workgroup).
+// HALF: the row spectra hold columns 0 .. N/2-1 only, column 0 packed as Y[m,0] + i Y[m,N/2] (see the forward
+// kernel); the upper half is rebuilt on load as the conjugate of the mirrored column (every stored line is
+// touched twice by the same workgroup, the second time from L1/L2).
 template <int LOGL, bool HALF>
 __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_packed_kernel(const RowArgs a,
                                                                                           const float2* __restrict__ tw_fwd) {
@@ -287,11 +288,16 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_pa
             if (HALF) {
                 const int m = n <= L / 2 ? n : L - n;  // stored column
                 sgn = n > L / 2 ? -1.0f : 1.0f;        // conjugate for the mirrored half
-                pidx = m == L / 2 ? L / 8 : (m >> 2);
+                pidx = m == L / 2 ? 0 : (m >> 2);
                 cidx = m == L / 2 ? 0 : (m & 3);
             }
             const float2* p = a.src_c + (size_t)pidx * a.pstride + (size_t)rr * 4 + cidx;
             float2 y0 = p[0], y1 = p[4], y2 = p[8], y3 = p[12];
+            if (HALF) {
+                const int m = n <= L / 2 ? n : L - n;
+                if (m == L / 2) { y0.x = y0.y; y1.x = y1.y; y2.x = y2.y; y3.x = y3.y; }      // Nyquist: imaginary part of the packed column
+                if (m == 0 || m == L / 2) { y0.y = 0.f; y1.y = 0.f; y2.y = 0.f; y3.y = 0.f; }  // both are real
+            }
             y0.y *= sgn; y1.y *= sgn; y2.y *= sgn; y3.y *= sgn;
             z[0][s] = make_float2(y0.x - y1.y, y0.y + y1.x);  // Y_a + i Y_b
             z[1][s] = make_float2(y2.x - y3.y, y2.y + y3.x);
@@ -465,15 +471,71 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PE
 // One panel of pass B' on register set `cur` (spectrum, first-step order) with the filter in `flt`
 // (last-step order): forward, multiply, then -- `flt` now free -- queue the NEXT panel's spectrum
 // into it, inverse, store, and queue the next panel's filter into `cur`.
+// Packed column (half-spectrum mode, column 0 of panel 0): the column carries c[m] = X[m,0] + i X[m,N/2] with both
+// parts real, so its transform is C = F0 + i FN with F0, FN Hermitian.  Separate them with the mirrored value
+// C[M-k] (one LDS round trip), filter each with its own W, and re-pack Z0 + i ZN; the inverse transform then
+// returns the two filtered real columns in the real and imaginary parts.  The filter slot of this column holds
+//   S[k] = W0[k] (0 < k < M/2),  S[k] = WN[M-k] (M/2 < k < M),  S[0] = (W0[0], WN[0]),  S[M/2] = (W0[M/2], WN[M/2])
+// (W0 = W[.,0], WN = W[.,N/2]; both Hermitian, their values at 0 and M/2 real), built by filter_packed_column_kernel.
+template <int LOGM, class Core, int SEQ>
+__device__ __forceinline__ void packed_column_filter(float2 (&cur)[4][8], const float2 (&flt)[4][8], float2* grp_lds, int tid) {
+    using St = Steps<LOGM>;
+    constexpr int M = St::L;
+    float2* bufc = grp_lds + (SEQ & 1) * St::BUF;
+    float2* bufs = grp_lds + ((SEQ + 1) & 1) * St::BUF;
+    __syncthreads();  // the other buffer was read by the last exchange of the forward transform
+#pragma unroll
+    for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+        for (int q = 0; q < Core::RHOL; ++q) {
+            const int k = Core::out_index(tid, u, q);
+            bufc[k] = cur[0][u * Core::RHOL + q];
+            bufs[k] = flt[0][u * Core::RHOL + q];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+        for (int q = 0; q < Core::RHOL; ++q) {
+            const int s = u * Core::RHOL + q;
+            const int k = Core::out_index(tid, u, q);
+            const int km = (M - k) & (M - 1);
+            const float2 c = cur[0][s], cm = bufc[km], sl = flt[0][s], sm = bufs[km];
+            const float2 f0 = make_float2(0.5f * (c.x + cm.x), 0.5f * (c.y - cm.y));
+            const float2 fn = make_float2(0.5f * (c.y + cm.y), 0.5f * (cm.x - c.x));
+            float2 w0, wn;
+            if (k == 0 || k == M / 2) { w0 = make_float2(sl.x, 0.f); wn = make_float2(sl.y, 0.f); }
+            else if (k < M / 2) { w0 = sl; wn = sm; }
+            else { w0 = make_float2(sm.x, -sm.y); wn = make_float2(sl.x, -sl.y); }
+            const float2 z0 = cmul_fma(f0, w0), zn = cmul_fma(fn, wn);
+            cur[0][s] = make_float2(z0.x - zn.y, z0.y + zn.x);
+        }
+    __syncthreads();  // both buffers were just read: the next exchange may overwrite either
+}
+
 template <int LOGM, class Core>
 __device__ __forceinline__ void panel_tile(float2 (&cur)[4][8], float2 (&flt)[4][8], float2* __restrict__ data,
                                            const float2* __restrict__ filt, float2* grp_lds, const typename Core::Bases& bases,
                                            const float2* __restrict__ tw_fwd, int tid, size_t poff, bool store_ok,
-                                           bool have_next, size_t next_poff) {
+                                           bool have_next, size_t next_poff, bool packed_tile, bool packed_group) {
     Core::template run<0, false>(cur, grp_lds, tw_fwd, bases, tid);
+    // column 0 of panel 0 in half-spectrum mode: uniform branch per workgroup (barriers inside); groups of the
+    // same workgroup that hold other panels run it on a scratch copy so that all of them meet the barriers
+    if (packed_tile) {
+        float2 keep[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) keep[s] = cur[0][s];
+        packed_column_filter<LOGM, Core, Core::SLOTS>(cur, flt, grp_lds, tid);
+        if (!packed_group) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) cur[0][s] = cmul_fma(keep[s], flt[0][s]);
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) cur[0][s] = cmul_fma(cur[0][s], flt[0][s]);
+    }
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        cur[0][s] = cmul_fma(cur[0][s], flt[0][s]);
         cur[1][s] = cmul_fma(cur[1][s], flt[1][s]);
         cur[2][s] = cmul_fma(cur[2][s], flt[2][s]);
         cur[3][s] = cmul_fma(cur[3][s], flt[3][s]);
@@ -493,7 +555,7 @@ __device__ __forceinline__ void panel_tile(float2 (&cur)[4][8], float2 (&flt)[4]
 template <int LOGM>
 __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::PIPE_WAVES_PER_SIMD) void fft_cols_panel_fused_kernel(
     float2* __restrict__ data, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const size_t pstride,
-    const int npanels, const int ntiles) {
+    const int npanels, const int ntiles, const int packed0) {
     using St = Steps<LOGM>;
     using Geo = PanelGeom<LOGM>;
     constexpr int G = Geo::G, T = St::T;
@@ -522,13 +584,13 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::PIPE_WAV
         int tn = t + gridDim.x;
         bool more = tn < ntiles, nok = false;
         size_t npoff = more ? poff_of(tn, nok) : 0;
-        panel_tile<LOGM, Core>(P, Q, data, filt, grp_lds, bases, tw_fwd, tid, poff, ok, more, npoff);
+        panel_tile<LOGM, Core>(P, Q, data, filt, grp_lds, bases, tw_fwd, tid, poff, ok, more, npoff, packed0 && t == 0, g == 0);
         if (!more) break;
         t = tn; poff = npoff; ok = nok;
         tn = t + gridDim.x;
         more = tn < ntiles;
         npoff = more ? poff_of(tn, nok) : 0;
-        panel_tile<LOGM, Core>(Q, P, data, filt, grp_lds, bases, tw_fwd, tid, poff, ok, more, npoff);
+        panel_tile<LOGM, Core>(Q, P, data, filt, grp_lds, bases, tw_fwd, tid, poff, ok, more, npoff, packed0 && t == 0, g == 0);
         if (!more) break;
         t = tn; poff = npoff; ok = nok;
     }
@@ -546,7 +608,7 @@ static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const floa
         int grid = (a.num_cu > 0 ? a.num_cu : 256) * Geo::PIPE_WG_PER_CU;
         if (a.no_pipeline || grid > ntiles) grid = ntiles;
         hipLaunchKernelGGL((fft_cols_panel_fused_kernel<LOGM>), dim3(grid), dim3(Geo::THREADS), 0, s, a.data, a.filt, tw, ps,
-                           npanels, ntiles);
+                           npanels, ntiles, a.packed0);
     } else {
         return hipErrorInvalidValue;
     }
