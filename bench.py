@@ -30,17 +30,20 @@ if ROOT not in sys.path:
 PKG = "parallel-implementation-of-frequency-domain-image-restoration-using-fft_amd"
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-# algorithmic bytes per padded pixel of each pass
+# Algorithmic bytes per padded pixel of each pass.  "full": the complex-to-complex
+# formulation of SURVEY.md 8d (56 B/px fused, 72 B/px in the reference's pass order).  "half": the default fast
+# path keeps only the non-redundant half of the Hermitian spectrum, so every spectrum / filter
+# access is 4 B per image pixel instead of 8 -- the bytes that formulation actually has to move.
 PASS_BYTES = {
-    "A rows: pad+FFT (real->complex)": 12,
-    "B cols: FFT+Wiener": 24,
-    "C rows: IFFT (complex)": 16,
-    "D cols: IFFT+real+minmax": 12,
-    "B' cols: FFT*W*IFFT": 24,
-    "C' rows: IFFT+real+minmax": 12,
-    "E normalize+crop": 8,
+    "full": {
+        "A rows: pad+FFT (real->complex)": 12, "B cols: FFT+Wiener": 24, "C rows: IFFT (complex)": 16,
+        "D cols: IFFT+real+minmax": 12, "B' cols: FFT*W*IFFT": 24, "C' rows: IFFT+real+minmax": 12, "E normalize+crop": 8,
+    },
+    "half": {
+        "A rows: pad+FFT (real->complex)": 8, "B' cols: FFT*W*IFFT": 12, "C' rows: IFFT+real+minmax": 8, "E normalize+crop": 8,
+    },
 }
-PIPELINE_BYTES = {"fast": 56, "parity": 72}
+PIPELINE_BYTES = {("fast", "half"): 36, ("fast", "full"): 56, ("parity", "full"): 72}
 SEEDS = {1024: 0x5EED0002, 4096: 0x5EED0003, 8192: 0x5EED0004, 2048: 0x5EED0005}
 
 
@@ -111,6 +114,9 @@ def main():
     seed = SEEDS.get(S, 0x5EED0000)
 
     flags = fdr.FLAG_NO_PIPELINE if os.environ.get("FDR_NO_PIPELINE") == "1" else 0
+    if os.environ.get("FDR_FULL_SPECTRUM") == "1":
+        flags |= fdr.FLAG_FULL_SPECTRUM
+    spectrum = "half" if (args.mode == "fast" and not (flags & fdr.FLAG_FULL_SPECTRUM) and S >= 32) else "full"
     plan = fdr.Plan(S, S, mode, device=local_rank, flags=flags)
     stream = torch.cuda.current_stream().cuda_stream
     plan.set_concurrency(args.streams)
@@ -143,12 +149,13 @@ def main():
     if rank == 0:
         images = world * B * args.steps
         value = images * P / 1e6 / elapsed
-        pipe_gbps = PIPELINE_BYTES[args.mode] * P * images / elapsed / 1e9
+        pipe_bpp = PIPELINE_BYTES[(args.mode, spectrum)]
+        pipe_gbps = pipe_bpp * P * images / elapsed / 1e9
         dom = max(passes, key=lambda t: t[1]) if passes else None
         roofline = None
         if dom:
             name, ms, cnt = dom
-            alg = PASS_BYTES.get(name, 0) * P
+            alg = PASS_BYTES[spectrum].get(name, 0) * P
             achieved = alg / (ms * 1e-3) / 1e9
             roofline = {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -156,14 +163,15 @@ def main():
                 "kernel": name, "kernel_ms": round(ms, 5), "launches_timed": cnt,
                 "algorithmic_bytes_per_launch": alg,
                 "all_passes_ms": {n: round(m, 5) for n, m, _ in passes},
-                "pipeline": {"bytes_per_pixel": PIPELINE_BYTES[args.mode], "achieved": round(pipe_gbps, 1),
-                             "frac": round(pipe_gbps / HBM_PEAK_GBPS, 4)},
+                "pipeline": {"bytes_per_pixel": pipe_bpp, "achieved": round(pipe_gbps, 1),
+                             "frac": round(pipe_gbps / HBM_PEAK_GBPS, 4),
+                             "full_complex_equivalent_GBps": round(PIPELINE_BYTES[(args.mode, "full")] * P * images / elapsed / 1e9, 1)},
             }
             tfile = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tfile):
                 try:
                     tj = json.load(open(tfile))
-                    key = "%s/%d" % (args.mode, S)
+                    key = "%s/%s/%d" % (args.mode, spectrum, S)
                     if key in tj and name in tj[key]:
                         roofline["traffic"] = tj[key][name]
                 except Exception:
@@ -174,7 +182,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%dx%d synthetic fp32, PSF len=50 angle=30, K=0.01, single channel, device-resident" % (S, S),
-                       "images_per_gpu_per_step": B, "mode": args.mode, "streams": args.streams, "parallelism": "images sharded over %d rank(s)" % world,
+                       "images_per_gpu_per_step": B, "mode": args.mode, "spectrum": spectrum, "streams": args.streams, "parallelism": "images sharded over %d rank(s)" % world,
                        "normalize_area": "padded (serial semantics)"},
             "roofline": roofline,
             "check": {"images_done": int(tot[0]), "checksum": tot[1], "ranks_ok": int(tot[2])},

@@ -478,7 +478,8 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PE
 //   S[k] = W0[k] (0 < k < M/2),  S[k] = WN[M-k] (M/2 < k < M),  S[0] = (W0[0], WN[0]),  S[M/2] = (W0[M/2], WN[M/2])
 // (W0 = W[.,0], WN = W[.,N/2]; both Hermitian, their values at 0 and M/2 real), built by filter_packed_column_kernel.
 template <int LOGM, class Core, int SEQ>
-__device__ __forceinline__ void packed_column_filter(float2 (&cur)[4][8], const float2 (&flt)[4][8], float2* grp_lds, int tid) {
+__device__ __forceinline__ void packed_column_filter(float2 (&cur)[4][8], const float2 (&flt)[4][8], float2* grp_lds, int tid,
+                                                     bool apply) {
     using St = Steps<LOGM>;
     constexpr int M = St::L;
     float2* bufc = grp_lds + (SEQ & 1) * St::BUF;
@@ -508,7 +509,8 @@ __device__ __forceinline__ void packed_column_filter(float2 (&cur)[4][8], const 
             else if (k < M / 2) { w0 = sl; wn = sm; }
             else { w0 = make_float2(sm.x, -sm.y); wn = make_float2(sl.x, -sl.y); }
             const float2 z0 = cmul_fma(f0, w0), zn = cmul_fma(fn, wn);
-            cur[0][s] = make_float2(z0.x - zn.y, z0.y + zn.x);
+            // thread groups of this workgroup that hold other panels only came along for the barriers
+            cur[0][s] = apply ? make_float2(z0.x - zn.y, z0.y + zn.x) : cmul_fma(c, sl);
         }
     __syncthreads();  // both buffers were just read: the next exchange may overwrite either
 }
@@ -519,17 +521,10 @@ __device__ __forceinline__ void panel_tile(float2 (&cur)[4][8], float2 (&flt)[4]
                                            const float2* __restrict__ tw_fwd, int tid, size_t poff, bool store_ok,
                                            bool have_next, size_t next_poff, bool packed_tile, bool packed_group) {
     Core::template run<0, false>(cur, grp_lds, tw_fwd, bases, tid);
-    // column 0 of panel 0 in half-spectrum mode: uniform branch per workgroup (barriers inside); groups of the
-    // same workgroup that hold other panels run it on a scratch copy so that all of them meet the barriers
+    // column 0 of panel 0 in half-spectrum mode: uniform branch per workgroup (barriers inside); thread groups of
+    // the same workgroup that hold other panels go through the same barriers and keep the plain product
     if (packed_tile) {
-        float2 keep[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) keep[s] = cur[0][s];
-        packed_column_filter<LOGM, Core, Core::SLOTS>(cur, flt, grp_lds, tid);
-        if (!packed_group) {
-#pragma unroll
-            for (int s = 0; s < 8; ++s) cur[0][s] = cmul_fma(keep[s], flt[0][s]);
-        }
+        packed_column_filter<LOGM, Core, Core::SLOTS>(cur, flt, grp_lds, tid, packed_group);
     } else {
 #pragma unroll
         for (int s = 0; s < 8; ++s) cur[0][s] = cmul_fma(cur[0][s], flt[0][s]);

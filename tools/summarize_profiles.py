@@ -74,7 +74,7 @@ def main():
             w.writerow(r)
     tj_path = os.path.join(dst, "traffic.json")
     tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
-    tj["%s/%d" % (mode, size)] = traffic
+    tj["%s/%d" % (mode, size)] = traffic  # mode like "fast/half" or "parity/full"
     json.dump(tj, open(tj_path, "w"), indent=1, sort_keys=True)
     bl = os.path.join(src, "bench_line.json")
     if os.path.exists(bl):
