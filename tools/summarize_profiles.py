@@ -5,7 +5,7 @@ traffic from the PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribe
 reads on gfx950, after checking that factor on a known-size float4 copy; WRITE_SIZE as is; both in
 KiB), and profiles/traffic.json, which bench.py reads to fill roofline.traffic.
 
-    python tools/summarize_profiles.py r01 fast 4096
+    python tools/summarize_profiles.py r01 fast/half 4096
 """
 import collections
 import csv
@@ -60,7 +60,8 @@ def main():
     rows = []
     for kname, vals in fe.items():
         for key, pname in PASS_OF.items():
-            if key in kname and ("<%d>" % (size.bit_length() - 1) in kname or key == "normalize_kernel"):
+            lg = size.bit_length() - 1
+            if key in kname and ("<%d>" % lg in kname or "<%d," % lg in kname or key == "normalize_kernel"):
                 rd = statistics.median(vals) * round(fetch_factor) * 1024.0
                 wv = [v for k, v in wr.items() if k == kname]
                 wt = statistics.median(wv[0]) * 1024.0 if wv else 0.0
