@@ -5,8 +5,11 @@
 // reference (fft/fft_gpu.cu:153-164, 214-240) and, in fast mode, also wiener_kernel (:169-181).
 //
 // A 128-byte line of the row-major M x N array is shared by 16/(4*G) workgroups; the tile map
-// below places those workgroups on the same XCD (blocks b, b+8, b+16.. share an L2) so the line
-// is fetched from / written back to the memory side once.  This only affects speed.
+// below places those workgroups on the same XCD (blocks b, b+8, b+16.. share an L2).  This only
+// affects speed, and it is not enough: with >= 128 KB of lines in flight per CU the sharing cannot
+// be served from a 4 MiB L2, which is why the fast mode moved to the panel-major layout of
+// fdr_panel.hip.  These kernels remain the parity-mode column passes (reference pass order) and the
+// FDR_FLAG_ROWMAJOR A/B variant of the fast mode.
 #include "fdr_fft_core.hpp"
 #include "fdr_kernels.hpp"
 
@@ -179,164 +182,6 @@ __global__ __launch_bounds__(ColGeom<LOGM>::THREADS, ColGeom<LOGM>::WAVES_PER_SI
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Fast-mode pass B', software-pipelined: a persistent workgroup (one per CU, <= 256 VGPRs) walks
-// over column tiles with TWO register sets whose roles alternate: while the forward transform of
-// tile i runs in one set, its filter W streams into the other; after the multiply that set is free
-// and receives the spectrum of tile i+1 during the inverse transform; after the store the first
-// set receives W of tile i+1.  Every CU keeps >= 128 KB of loads in flight behind its butterflies.  This only works because the fast policy
-// issues no vector-memory load inside the transform (hoisted twiddle bases): vmcnt retires in
-// order, so any load consumed inside the FFT would first drain the prefetch queued before it.
-// ---------------------------------------------------------------------------------------------
-template <int LOGM>
-struct PipeGeom {
-    using Geo = ColGeom<LOGM>;
-    static constexpr int THREADS = Geo::THREADS;
-    static constexpr int WAVES_PER_SIMD = THREADS >= 512 ? 2 : 1;  // 512 threads: 8 waves = 2 per SIMD, 256 VGPRs each
-    static constexpr int WG_PER_CU = THREADS >= 512 ? 1 : 512 / THREADS;
-};
-
-// Loads are unconditional (no exec-mask branches around 16 wide loads): a thread group whose columns
-// lie beyond N reads columns 0..3 instead -- valid memory, results never stored.
-template <class Core>
-__device__ __forceinline__ void pipe_load_in(const float2* __restrict__ base, int N, int col0, bool active, int tid,
-                                             float2 (&d)[4][8]) {
-    if (!active) col0 = 0;
-#pragma unroll
-    for (int u = 0; u < Core::NU0; ++u) {
-        const unsigned toff = (unsigned)(tid + u * Core::T) * (unsigned)N + (unsigned)col0;
-#pragma unroll
-        for (int q = 0; q < Core::RHO0; ++q) {
-            const int s = u * Core::RHO0 + q;
-            const float2* bq = base + (size_t)(q << Core::LOGR0) * (size_t)N;  // wave-uniform
-            load4(bq + toff, d[0][s], d[1][s], d[2][s], d[3][s]);
-        }
-    }
-}
-template <class Core>
-__device__ __forceinline__ void pipe_load_out(const float2* __restrict__ base, int N, int col0, bool active, int tid,
-                                              float2 (&d)[4][8]) {
-    if (!active) col0 = 0;
-#pragma unroll
-    for (int u = 0; u < Core::NUL; ++u) {
-        const unsigned toff = (unsigned)(tid + u * Core::T) * (unsigned)N + (unsigned)col0;
-#pragma unroll
-        for (int q = 0; q < Core::RHOL; ++q) {
-            const int s = u * Core::RHOL + q;
-            const float2* bq = base + (size_t)(q << Core::LOGOUT) * (size_t)N;  // wave-uniform
-            load4(bq + toff, d[0][s], d[1][s], d[2][s], d[3][s]);
-        }
-    }
-}
-template <class Core>
-__device__ __forceinline__ void pipe_store_out(float2* __restrict__ base, int N, int col0, bool active, int tid,
-                                               const float2 (&d)[4][8]) {
-    if (!active) return;
-#pragma unroll
-    for (int u = 0; u < Core::NUL; ++u) {
-        const unsigned toff = (unsigned)(tid + u * Core::T) * (unsigned)N + (unsigned)col0;
-#pragma unroll
-        for (int q = 0; q < Core::RHOL; ++q) {
-            const int s = u * Core::RHOL + q;
-            float2* bq = base + (size_t)(q << Core::LOGOUT) * (size_t)N;
-            store4(bq + toff, d[0][s], d[1][s], d[2][s], d[3][s]);
-        }
-    }
-}
-
-// One tile of pass B' on register set `cur` (spectrum, first-step order) with the filter in `flt`
-// (last-step order): forward columns, multiply, then -- with `flt` free -- queue the NEXT tile's
-// spectrum into it, inverse columns, store, and queue the next tile's filter into `cur`.
-// Register roles therefore alternate between two sets only (128 VGPRs of payload).
-template <int LOGM, class Core>
-__device__ __forceinline__ void pipe_tile(float2 (&cur)[4][8], float2 (&flt)[4][8], const ColArgs& a, float2* grp_lds,
-                                          const typename Core::Bases& bases, const float2* __restrict__ tw_fwd, int tid,
-                                          int col0, int next_col0 /* < 0: none */) {
-    using St = Steps<LOGM>;
-    constexpr int B = 4;
-    const int N = a.N;
-    Core::template run<0, false>(cur, grp_lds, tw_fwd, bases, tid);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        cur[0][s] = cmul_fma(cur[0][s], flt[0][s]);
-        cur[1][s] = cmul_fma(cur[1][s], flt[1][s]);
-        cur[2][s] = cmul_fma(cur[2][s], flt[2][s]);
-        cur[3][s] = cmul_fma(cur[3][s], flt[3][s]);
-    }
-    if (next_col0 >= 0) pipe_load_in<Core>(a.data, N, next_col0, next_col0 < N, tid, flt);
-    constexpr int SEQ1 = Core::SLOTS;
-    if constexpr (Core::RHOL != Core::RHO0) {
-#pragma unroll
-        for (int b = 0; b < B; ++b) {
-            float2* buf = grp_lds + ((SEQ1 + b) & 1) * St::BUF;
-#pragma unroll
-            for (int u = 0; u < Core::NUL; ++u)
-#pragma unroll
-                for (int q = 0; q < Core::RHOL; ++q) buf[Core::out_index(tid, u, q)] = cur[b][u * Core::RHOL + q];
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < Core::NU0; ++u)
-#pragma unroll
-                for (int q = 0; q < Core::RHO0; ++q) cur[b][u * Core::RHO0 + q] = buf[Core::in_index(tid, u, q)];
-        }
-        Core::template run<SEQ1 + B, true>(cur, grp_lds, tw_fwd, bases, tid);
-    } else {
-        Core::template run<SEQ1, true>(cur, grp_lds, tw_fwd, bases, tid);
-    }
-    pipe_store_out<Core>(a.data, N, col0, col0 < N, tid, cur);
-    if (next_col0 >= 0) pipe_load_out<Core>(a.filt, N, next_col0, next_col0 < N, tid, cur);
-}
-
-template <int LOGM>
-__global__ __launch_bounds__(PipeGeom<LOGM>::THREADS, PipeGeom<LOGM>::WAVES_PER_SIMD) void fft_cols_fused_pipe_kernel(
-    const ColArgs a, const float2* __restrict__ tw_fwd, const int ntiles) {
-    using St = Steps<LOGM>;
-    using Geo = ColGeom<LOGM>;
-    constexpr int B = Geo::B, G = Geo::G, T = St::T;
-    using Core = FftCore<LOGM, B, 2, PolicyFast>;
-    static_assert(B == 4, "register sets are written for 4 columns per thread group");
-    __shared__ float2 lds[G * 2 * St::BUF];
-
-    const int N = a.N;
-    const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
-    float2* grp_lds = lds + g * 2 * St::BUF;
-    // in every round the SHARE workgroups that share 128-byte lines run on one XCD
-    int t = col_tile_of_block(blockIdx.x, gridDim.x, Geo::SHARE);
-    if (t >= ntiles) return;  // uniform over the workgroup
-
-    typename Core::Bases bases;
-    Core::init_bases(bases, tw_fwd, tid);
-
-    float2 P[B][8], Q[B][8];
-    {
-        const int col0 = (t * G + g) * B;
-        pipe_load_in<Core>(a.data, N, col0, col0 < N, tid, P);
-        pipe_load_out<Core>(a.filt, N, col0, col0 < N, tid, Q);
-    }
-    while (true) {
-        int tn = t + gridDim.x;
-        bool more = tn < ntiles;
-        pipe_tile<LOGM, Core>(P, Q, a, grp_lds, bases, tw_fwd, tid, (t * G + g) * B, more ? (tn * G + g) * B : -1);
-        if (!more) break;
-        t = tn;
-        tn = t + gridDim.x;
-        more = tn < ntiles;
-        pipe_tile<LOGM, Core>(Q, P, a, grp_lds, bases, tw_fwd, tid, (t * G + g) * B, more ? (tn * G + g) * B : -1);
-        if (!more) break;
-        t = tn;
-    }
-}
-
-template <int LOGM>
-static hipError_t launch_cols_fused_pipe(const ColArgs& a, const float2* twf, hipStream_t s) {
-    using Geo = ColGeom<LOGM>;
-    const int ntiles = (a.N + Geo::COLS - 1) / Geo::COLS;
-    int grid = (a.num_cu > 0 ? a.num_cu : 256) * PipeGeom<LOGM>::WG_PER_CU;
-    if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL((fft_cols_fused_pipe_kernel<LOGM>), dim3(grid), dim3(Geo::THREADS), 0, s, a, twf, ntiles);
-    return hipGetLastError();
-}
-
 template <int LOGM, class Pol, int KIND>
 static hipError_t launch_cols_one(const ColArgs& a, const float2* twf, const float2* twi, hipStream_t s) {
     using Geo = ColGeom<LOGM>;
@@ -360,10 +205,7 @@ static hipError_t launch_cols_kind(int mode, ColKind kind, const ColArgs& a, con
     switch (kind) {
         case COL_FWD: return launch_cols_one<LOGM, PolicyFast, COL_FWD>(a, twf, twi, s);
         case COL_INV: return launch_cols_one<LOGM, PolicyFast, COL_INV>(a, twf, twi, s);
-        case COL_FUSED:
-            // 8192-point columns need 1024 threads (128 VGPRs): no room for a second register set
-            if constexpr (LOGM <= 12) { if (!a.no_pipeline) return launch_cols_fused_pipe<LOGM>(a, twf, s); }
-            return launch_cols_one<LOGM, PolicyFast, COL_FUSED>(a, twf, twi, s);
+        case COL_FUSED: return launch_cols_one<LOGM, PolicyFast, COL_FUSED>(a, twf, twi, s);  // FDR_FLAG_ROWMAJOR only
         default: return hipErrorInvalidValue;
     }
 }

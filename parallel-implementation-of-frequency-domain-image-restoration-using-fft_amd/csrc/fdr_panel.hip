@@ -591,6 +591,86 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::PIPE_WAV
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pass B' for 8192-point columns: one transform needs 1024 threads, i.e. 16 waves = 4 per SIMD and a
+// 128-VGPR budget, which cannot hold two register sets (the pipelined kernel above spills ~1 KB per
+// lane there).  This variant keeps ONE set (64 VGPRs of payload) and pulls the filter in 32-byte pieces
+// straight into the multiply, one workgroup per panel.
+// ---------------------------------------------------------------------------------------------
+template <int LOGM>
+__global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PER_SIMD) void fft_cols_panel_fused_lean_kernel(
+    float2* __restrict__ data, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const size_t pstride,
+    const int npanels, const int packed0) {
+    using St = Steps<LOGM>;
+    using Geo = PanelGeom<LOGM>;
+    constexpr int G = Geo::G, T = St::T, M = St::L;
+    using Core = FftCore<LOGM, 4, 2, PolicyFast>;
+    __shared__ float2 lds[G * 2 * St::BUF];
+    const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
+    float2* grp_lds = lds + g * 2 * St::BUF;
+    const int p = blockIdx.x * G + g;
+    const bool active = p < npanels;
+    const size_t poff = (size_t)(active ? p : 0) * pstride;
+
+    typename Core::Bases bases;
+    Core::init_bases(bases, tw_fwd, tid);
+
+    float2 v[4][8];
+    panel_load_in<Core>(data + poff, tid, v);
+    Core::template run<0, false>(v, grp_lds, tw_fwd, bases, tid);
+
+    const bool packed_tile = packed0 && blockIdx.x == 0;  // uniform per workgroup
+    constexpr int SEQ = Core::SLOTS;
+    float2* bufc = grp_lds + (SEQ & 1) * St::BUF;
+    float2* bufs = grp_lds + ((SEQ + 1) & 1) * St::BUF;
+    if (packed_tile) {  // mirror exchange of the packed column and of its filter slot column (see packed_column_filter)
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+            for (int q = 0; q < Core::RHOL; ++q) {
+                const int k = Core::out_index(tid, u, q);
+                bufc[k] = v[0][u * Core::RHOL + q];
+                bufs[k] = filt[poff + (size_t)k * 4];
+            }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+        for (int q = 0; q < Core::RHOL; ++q) {
+            const int s = u * Core::RHOL + q;
+            const int k = Core::out_index(tid, u, q);
+            float2 w0, w1, w2, w3;
+            load4(filt + poff + (size_t)k * 4, w0, w1, w2, w3);
+            if (packed_tile && g == 0) {
+                const int km = (M - k) & (M - 1);
+                const float2 c = v[0][s], cm = bufc[km], sl = w0, sm = bufs[km];
+                const float2 f0 = make_float2(0.5f * (c.x + cm.x), 0.5f * (c.y - cm.y));
+                const float2 fn = make_float2(0.5f * (c.y + cm.y), 0.5f * (cm.x - c.x));
+                float2 a0, an;
+                if (k == 0 || k == M / 2) { a0 = make_float2(sl.x, 0.f); an = make_float2(sl.y, 0.f); }
+                else if (k < M / 2) { a0 = sl; an = sm; }
+                else { a0 = make_float2(sm.x, -sm.y); an = make_float2(sl.x, -sl.y); }
+                const float2 z0 = cmul_fma(f0, a0), zn = cmul_fma(fn, an);
+                v[0][s] = make_float2(z0.x - zn.y, z0.y + zn.x);
+            } else {
+                v[0][s] = cmul_fma(v[0][s], w0);
+            }
+            v[1][s] = cmul_fma(v[1][s], w1);
+            v[2][s] = cmul_fma(v[2][s], w2);
+            v[3][s] = cmul_fma(v[3][s], w3);
+        }
+    if (packed_tile) __syncthreads();  // both buffers were read above
+    if constexpr (Core::RHOL != Core::RHO0) {
+        redistribute<LOGM, Core, SEQ>(v, grp_lds, tid);
+        Core::template run<SEQ + 4, true>(v, grp_lds, tw_fwd, bases, tid);
+    } else {
+        Core::template run<SEQ, true>(v, grp_lds, tw_fwd, bases, tid);
+    }
+    if (active) panel_store_out<Core>(data + poff, tid, v);
+}
+
 template <int LOGM>
 static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const float2* tw, hipStream_t s) {
     using Geo = PanelGeom<LOGM>;
@@ -600,6 +680,11 @@ static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const floa
     if (kind == COL_FWD) {
         hipLaunchKernelGGL((fft_cols_panel_fwd_kernel<LOGM>), dim3(ntiles), dim3(Geo::THREADS), 0, s, a.data, tw, ps, npanels);
     } else if (kind == COL_FUSED) {
+        if constexpr (Geo::THREADS >= 1024) {  // 8192-point columns: single register set, one workgroup per panel
+            hipLaunchKernelGGL((fft_cols_panel_fused_lean_kernel<LOGM>), dim3(ntiles), dim3(Geo::THREADS), 0, s, a.data, a.filt, tw,
+                               ps, npanels, a.packed0);
+            return hipGetLastError();
+        }
         int grid = (a.num_cu > 0 ? a.num_cu : 256) * Geo::PIPE_WG_PER_CU;
         if (a.no_pipeline || grid > ntiles) grid = ntiles;
         hipLaunchKernelGGL((fft_cols_panel_fused_kernel<LOGM>), dim3(grid), dim3(Geo::THREADS), 0, s, a.data, a.filt, tw, ps,
