@@ -318,3 +318,30 @@ def test_drop_in_cli(fdr, tmp_path):
     assert subprocess.run([_os.path.join(root, "tools", "cli", "gpu")], capture_output=True).returncode == 255
     bad = subprocess.run([_os.path.join(root, "tools", "cli", "gpu"), "/nonexistent.png", "40", "45"], capture_output=True, text=True)
     assert bad.returncode == 255 and "Cannot read image" in bad.stdout
+
+
+@pytest.mark.parametrize("shape", [(8, 8), (16, 32), (32, 16), (8, 64), (64, 8), (32, 32), (5, 7), (33, 17), (1, 100), (100, 1)])
+@pytest.mark.parametrize("mode_name", ["MODE_PARITY", "MODE_FAST"])
+def test_small_and_ragged_shapes(fdr, oracle, shape, mode_name):
+    """Edge shapes: below the register-kernel threshold (simple path), exactly at the half-spectrum threshold
+    (N = 32), non powers of two, single rows / columns."""
+    psf = oracle.motion_blur_kernel(3, 30.0)
+    if shape[0] < 3 or shape[1] < 3:
+        psf = np.ones((1, 1), np.float32)
+    img = _image(oracle, shape[0], shape[1], 0xABC)
+    ref = oracle.serial_channel(img, psf, 0.01)
+    got = fdr.wienerDeblur_myfft(img, psf, 0.01, mode=getattr(fdr, mode_name))
+    if mode_name == "MODE_PARITY":
+        _assert_same(got, ref, "small shape %s" % (shape,))
+    else:
+        assert np.abs(got - ref).max() <= TOL, np.abs(got - ref).max()
+
+
+def test_constant_image_normalises_to_zero(fdr, oracle):
+    """smax - smin <= DBL_EPSILON -> scale 0 (cv::normalize); a 1x1 delta PSF keeps a constant image constant"""
+    img = np.zeros((16, 16), np.float32)
+    psf = np.ones((1, 1), np.float32)
+    for mode in (fdr.MODE_PARITY, fdr.MODE_FAST):
+        got = fdr.wienerDeblur_myfft(img, psf, 0.01, mode=mode)
+        _assert_same(got, oracle.serial_channel(img, psf, 0.01), "constant image")
+        assert np.all(got == 0.0)
