@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--mode", choices=["fast", "parity"], default="fast")
     ap.add_argument("--streams", type=int, default=2, help="internal streams / workspaces the batch alternates over")
+    ap.add_argument("--group", type=int, default=2, help="images per pass-B' launch (fast mode; 1..4, streams*group <= 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=0, help="edge of the CPU-baseline sample (default: --size, capped at 4096)")
     return ap.parse_args()
@@ -116,10 +117,12 @@ def main():
     flags = fdr.FLAG_NO_PIPELINE if os.environ.get("FDR_NO_PIPELINE") == "1" else 0
     if os.environ.get("FDR_FULL_SPECTRUM") == "1":
         flags |= fdr.FLAG_FULL_SPECTRUM
+    if os.environ.get("FDR_LEAN_COLS") == "1":
+        flags |= fdr.FLAG_LEAN_COLS
     spectrum = "half" if (args.mode == "fast" and not (flags & fdr.FLAG_FULL_SPECTRUM) and S >= 32) else "full"
     plan = fdr.Plan(S, S, mode, device=local_rank, flags=flags)
     stream = torch.cuda.current_stream().cuda_stream
-    plan.set_concurrency(args.streams)
+    plan.set_batching(args.streams, args.group if args.mode == "fast" else 1)
     plan.set_psf_motion(50, 30.0, 0.01, stream=stream)  # PSF generated, padded and transformed on the device
     imgs = torch.empty((B, S, S), dtype=torch.float32, device=dev)
     outs = torch.empty((B, S, S), dtype=torch.float32, device=dev)
@@ -151,11 +154,16 @@ def main():
         value = images * P / 1e6 / elapsed
         pipe_bpp = PIPELINE_BYTES[(args.mode, spectrum)]
         pipe_gbps = pipe_bpp * P * images / elapsed / 1e9
-        dom = max(passes, key=lambda t: t[1]) if passes else None
+        dom = max(passes, key=lambda t: t[1]) if passes else None  # longest launch
         roofline = None
         if dom:
             name, ms, cnt = dom
-            alg = PASS_BYTES[spectrum].get(name, 0) * P
+            # a grouped pass-B' launch ("... [k images]") moves k images' worth of bytes
+            base_name, nimg = name, 1
+            if name.endswith(" images]"):
+                base_name, tail = name.rsplit(" [", 1)
+                nimg = int(tail.split()[0])
+            alg = PASS_BYTES[spectrum].get(base_name, 0) * P * nimg
             achieved = alg / (ms * 1e-3) / 1e9
             roofline = {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -172,8 +180,8 @@ def main():
                 try:
                     tj = json.load(open(tfile))
                     key = "%s/%s/%d" % (args.mode, spectrum, S)
-                    if key in tj and name in tj[key]:
-                        roofline["traffic"] = tj[key][name]
+                    if key in tj and base_name in tj[key]:
+                        roofline["traffic"] = tj[key][base_name] * nimg
                 except Exception:
                     pass
         line = {
@@ -182,7 +190,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%dx%d synthetic fp32, PSF len=50 angle=30, K=0.01, single channel, device-resident" % (S, S),
-                       "images_per_gpu_per_step": B, "mode": args.mode, "spectrum": spectrum, "streams": args.streams, "parallelism": "images sharded over %d rank(s)" % world,
+                       "images_per_gpu_per_step": B, "mode": args.mode, "spectrum": spectrum, "streams": args.streams, "images_per_B_launch": args.group, "parallelism": "images sharded over %d rank(s)" % world,
                        "normalize_area": "padded (serial semantics)"},
             "roofline": roofline,
             "check": {"images_done": int(tot[0]), "checksum": tot[1], "ranks_ok": int(tot[2])},

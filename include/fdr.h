@@ -57,6 +57,11 @@ extern "C" {
 #define FDR_FLAG_FULL_SPECTRUM 32u /* fast mode: keep all N columns of the (Hermitian) spectrum instead of
                                       N/2 + 1 (A/B measurements; implied by NO_PACKING and ROWMAJOR)     */
 
+#define FDR_FLAG_LEAN_COLS 64u /* fast mode: pass B' with one register set and one workgroup per column tile, two
+                                  workgroups per CU (the hardware overlaps one tile's memory phases with the other's
+                                  transforms) instead of the persistent software-pipelined kernel (A/B measurements;
+                                  always used for 8192-point columns)                                              */
+
 /* normalisation area selector for fdr_wiener_* */
 #define FDR_NORM_PADDED 1  /* serial semantics: min/max over the padded M x N area, then crop
                               (serial.cpp:36-38 + fft/fft_serial.cpp:243-246)                 */
@@ -114,6 +119,10 @@ int fdr_wiener_batch_f32_dev(fdr_plan* plan, const float* d_imgs, size_t img_pit
  * so one image's kernel tails overlap the next image's kernel heads.  Costs (nstreams-1) extra
  * workspaces of 12 bytes per padded pixel.  Default 1.                                         */
 int fdr_plan_set_concurrency(fdr_plan* plan, int nstreams);
+/* The same with `group` (1..4) images per pass-B' launch in the fast mode: the persistent column kernel then
+ * walks the panels of `group` images in one go (its prologue / epilogue amortise, and small images fill the
+ * chip).  nstreams * group <= 8 workspaces.  fdr_plan_set_concurrency(n) == fdr_plan_set_batching(n, 1).   */
+int fdr_plan_set_batching(fdr_plan* plan, int nstreams, int group);
 
 /* -- fft_gpu::my_dft2D(Mat&, bool) (fft/fft.hpp:40; empty body at fft/fft_gpu.cu:515):
  *    in-place unscaled 2-D transform of M x N interleaved complex.                       */

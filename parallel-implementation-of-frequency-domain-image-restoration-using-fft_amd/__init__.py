@@ -26,6 +26,7 @@ FLAG_ROWMAJOR = 4
 FLAG_NO_PACKING = 8
 FLAG_POW2_PANELS = 16
 FLAG_FULL_SPECTRUM = 32
+FLAG_LEAN_COLS = 64
 NORM_PADDED = 1
 NORM_CROPPED = 0
 MAX_PASSES = 8
@@ -82,6 +83,7 @@ def _load():
     L.fdr_wiener_f32_dev.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, vp]
     L.fdr_wiener_batch_f32_dev.argtypes = [vp, vp, ctypes.c_size_t, ci, ci, ci, ci, vp, ctypes.c_size_t, ci, ci, vp]
     L.fdr_plan_set_concurrency.argtypes = [vp, ci]
+    L.fdr_plan_set_batching.argtypes = [vp, ci, ci]
     L.fdr_fft2d_c2c.argtypes = [vp, vp, ci]
     L.fdr_fft2d_c2c_dev.argtypes = [vp, vp, ci, vp]
     L.fdr_fft1d_c2c.argtypes = [vp, ci, ci, ci]
@@ -91,8 +93,8 @@ def _load():
     L.fdr_plan_pass_times.argtypes = [vp, ctypes.POINTER(ci), _f32p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ci)]
     for name in ("fdr_device_count", "fdr_next_pow2", "fdr_is_pow2", "fdr_plan_create", "fdr_plan_destroy", "fdr_plan_dims",
                  "fdr_psf_motion", "fdr_psf_motion_dev", "fdr_set_psf", "fdr_set_psf_dev", "fdr_set_psf_motion",
-                 "fdr_wiener_f32", "fdr_wiener_f32_dev", "fdr_wiener_batch_f32_dev", "fdr_plan_set_concurrency", "fdr_fft2d_c2c",
-                 "fdr_fft2d_c2c_dev", "fdr_fft1d_c2c", "fdr_dft_naive_c2c", "fdr_synth_image_dev", "fdr_plan_profile", "fdr_plan_pass_times"):
+                 "fdr_wiener_f32", "fdr_wiener_f32_dev", "fdr_wiener_batch_f32_dev", "fdr_plan_set_concurrency", "fdr_plan_set_batching",
+                 "fdr_fft2d_c2c", "fdr_fft2d_c2c_dev", "fdr_fft1d_c2c", "fdr_dft_naive_c2c", "fdr_synth_image_dev", "fdr_plan_profile", "fdr_plan_pass_times"):
         getattr(L, name).restype = ci
     return L
 
@@ -103,7 +105,7 @@ EXPORTED_SYMBOLS = (
     "fdr_version", "fdr_last_error", "fdr_device_count", "fdr_next_pow2", "fdr_is_pow2", "fdr_plan_create",
     "fdr_plan_destroy", "fdr_plan_dims", "fdr_psf_motion", "fdr_psf_motion_dev", "fdr_set_psf", "fdr_set_psf_dev",
     "fdr_set_psf_motion", "fdr_wiener_f32", "fdr_wiener_f32_dev", "fdr_wiener_batch_f32_dev", "fdr_plan_set_concurrency",
-    "fdr_fft2d_c2c",
+    "fdr_plan_set_batching", "fdr_fft2d_c2c",
     "fdr_fft2d_c2c_dev", "fdr_fft1d_c2c", "fdr_dft_naive_c2c", "fdr_synth_image_dev", "fdr_plan_profile",
     "fdr_plan_pass_times")
 
@@ -211,6 +213,10 @@ class Plan:
     def set_concurrency(self, nstreams):
         """Batched mode: alternate images over `nstreams` private workspaces / internal streams."""
         _check(lib.fdr_plan_set_concurrency(self._h, int(nstreams)))
+
+    def set_batching(self, nstreams, group):
+        """Batched mode: `nstreams` internal streams, `group` images per pass-B' launch (fast mode)."""
+        _check(lib.fdr_plan_set_batching(self._h, int(nstreams), int(group)))
 
     # transforms
     def fft2d(self, x, inverse=False):

@@ -130,9 +130,11 @@ struct fdr_plan {
         float2* work = nullptr; float2* work2 = nullptr; float* raw = nullptr; float* mm = nullptr; float2* mm_part = nullptr;
         hipStream_t stream = nullptr; hipEvent_t done = nullptr;
     };
-    static constexpr int kMaxSlots = 4;
+    static constexpr int kMaxSlots = 8;
     Slot slots[kMaxSlots];
-    int nslots = 1;
+    int nslots = 1;   // = nstreams * group
+    int nstreams = 1;
+    int group = 1;    // images per pass-B' launch (panel path)
     hipEvent_t fork = nullptr;
     size_t ws_elems = 0;  // elements of one work / raw buffer
 };
@@ -159,6 +161,8 @@ const char* const kPassColsWiener = "B cols: FFT+Wiener";
 const char* const kPassRowsInv = "C rows: IFFT (complex)";
 const char* const kPassColsInvReal = "D cols: IFFT+real+minmax";
 const char* const kPassColsFused = "B' cols: FFT*W*IFFT";
+const char* const kPassColsFusedN[5] = {nullptr, kPassColsFused, "B' cols: FFT*W*IFFT [2 images]", "B' cols: FFT*W*IFFT [3 images]",
+                                       "B' cols: FFT*W*IFFT [4 images]"};
 const char* const kPassRowsInvReal = "C' rows: IFFT+real+minmax";
 const char* const kPassNormalize = "E normalize+crop";
 const char* const kPassSimple = "simple path (reference-shaped)";
@@ -227,12 +231,56 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
     return FDR_OK;
 }
 
-int wiener_dev_impl(fdr_plan* p, const fdr_plan::Slot& w, const float* d_img, int rows, int cols, int stride, float* d_out,
-                    int out_stride, int norm_area, hipStream_t s) {
+// ---- fast panel path in three stages, so that pass B' can be launched once for a group of images ----
+int panel_stage_A(fdr_plan* p, const fdr_plan::Slot& w, const float* d_img, int rows, int cols, int stride, hipStream_t s) {
+    ScopedPass t(p, s, kPassRowsFwd);   // A: 4 rows per thread group, real -> panel-major (half) spectrum
+    RowArgs a{};
+    a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
+    a.dst_c = w.work; a.M = p->M; a.no_packing = p->no_packing; a.pstride = p->pstride; a.half = p->half;
+    FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
+    return FDR_OK;
+}
+int panel_stage_B(fdr_plan* p, const fdr_plan::Slot* const* ws, int n, hipStream_t s) {
+    ScopedPass t(p, s, kPassColsFusedN[n]);  // B': per panel, columns forward * W * inverse, persistent + double-buffered
+    ColArgs c{};
+    c.data = ws[0]->work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu; c.no_pipeline = p->no_pipeline;
+    c.lean = (p->flags & FDR_FLAG_LEAN_COLS) != 0;
+    c.pstride = p->pstride; c.npanels = p->npanels; c.packed0 = p->half ? 1 : 0;
+    c.batch.nimg = n;
+    for (int k = 0; k < n; ++k) c.batch.data[k] = ws[k]->work;
+    FDR_HIP(launch_cols_panel(p->logM, COL_FUSED, c, p->tw_col_f, s));
+    return FDR_OK;
+}
+int panel_stage_CE(fdr_plan* p, const fdr_plan::Slot& w, int rows, int cols, float* d_out, int out_stride, int mm_rows,
+                   int mm_cols, hipStream_t s) {
+    {   // C': 4 rows rebuilt from the panels, inverse, real plane, min/max partials
+        ScopedPass t(p, s, kPassRowsInvReal);
+        RowArgs a{};
+        a.src_c = w.work; a.dst_real = w.raw; a.mm_part = w.mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
+        a.no_packing = p->no_packing; a.pstride = p->pstride; a.half = p->half;
+        FDR_HIP(launch_rows4(p->logN, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, a, p->tw_row_f, s));
+    }
+    {   // E: normalise to [0,1] and crop
+        ScopedPass t(p, s, kPassNormalize);
+        const int n_part = rows4_minmax_partials(p->logN, p->M);
+        if (n_part <= 0 || n_part > p->mm_part_cap || n_part > 4096) return fail(FDR_ERR_STATE, "fdr_wiener: min/max partial count out of range");
+        FDR_HIP(launch_normalize(w.raw, p->N, w.mm_part, n_part, nullptr, d_out, rows, cols, out_stride, s));
+    }
+    return FDR_OK;
+}
+
+int check_image_args(fdr_plan* p, const float* d_img, int rows, int cols, int stride, float* d_out, int out_stride) {
     if (!p->have_psf) return fail(FDR_ERR_STATE, "fdr_wiener: no PSF set on this plan (call fdr_set_psf* first)");
     if (!d_img || !d_out) return fail(FDR_ERR_ARG, "fdr_wiener: null image pointer");
     if (rows <= 0 || cols <= 0 || rows > p->M || cols > p->N || stride < cols || out_stride < cols)
         return fail(FDR_ERR_ARG, "fdr_wiener: image shape does not fit the plan");
+    return FDR_OK;
+}
+
+int wiener_dev_impl(fdr_plan* p, const fdr_plan::Slot& w, const float* d_img, int rows, int cols, int stride, float* d_out,
+                    int out_stride, int norm_area, hipStream_t s) {
+    int vrc = check_image_args(p, d_img, rows, cols, stride, d_out, out_stride);
+    if (vrc != FDR_OK) return vrc;
     const int mm_rows = norm_area == FDR_NORM_PADDED ? p->M : rows;
     const int mm_cols = norm_area == FDR_NORM_PADDED ? p->N : cols;
     const size_t P = (size_t)p->M * p->N;
@@ -275,26 +323,11 @@ int wiener_dev_impl(fdr_plan* p, const fdr_plan::Slot& w, const float* d_img, in
             n_part = cols_minmax_partials(p->logM, p->N);
         }
     } else if (p->panel) {
-        {   // A: 4 rows per thread group, real -> panel-major spectrum
-            ScopedPass t(p, s, kPassRowsFwd);
-            RowArgs a{};
-            a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
-            a.dst_c = w.work; a.M = p->M; a.no_packing = p->no_packing; a.pstride = p->pstride; a.half = p->half;
-            FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
-        }
-        {   // B': per panel, columns forward * W * inverse, persistent + register double-buffered
-            ScopedPass t(p, s, kPassColsFused);
-            ColArgs c{};
-            c.data = w.work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu; c.no_pipeline = p->no_pipeline; c.pstride = p->pstride; c.npanels = p->npanels; c.packed0 = p->half ? 1 : 0;
-            FDR_HIP(launch_cols_panel(p->logM, COL_FUSED, c, p->tw_col_f, s));
-        }
-        {   // C': 4 rows gathered from the panels, inverse, real plane, min/max
-            ScopedPass t(p, s, kPassRowsInvReal);
-            RowArgs a{};
-            a.src_c = w.work; a.dst_real = w.raw; a.mm_part = w.mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M; a.no_packing = p->no_packing; a.pstride = p->pstride; a.half = p->half;
-            FDR_HIP(launch_rows4(p->logN, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, a, p->tw_row_f, s));
-            n_part = rows4_minmax_partials(p->logN, p->M);
-        }
+        const fdr_plan::Slot* one[1] = {&w};
+        int rc = panel_stage_A(p, w, d_img, rows, cols, stride, s);
+        if (rc == FDR_OK) rc = panel_stage_B(p, one, 1, s);
+        if (rc == FDR_OK) rc = panel_stage_CE(p, w, rows, cols, d_out, out_stride, mm_rows, mm_cols, s);
+        return rc;
     } else {
         {   // A
             ScopedPass t(p, s, kPassRowsFwd);
@@ -493,41 +526,57 @@ int fdr_wiener_batch_f32_dev(fdr_plan* p, const float* d_imgs, size_t img_pitch,
                              float* d_out, size_t out_pitch, int out_stride, int norm_area, void* stream) {
     if (!p) return fail(FDR_ERR_ARG, "fdr_wiener_batch_f32_dev: null plan");
     if (count < 0) return fail(FDR_ERR_ARG, "fdr_wiener_batch_f32_dev: negative count");
+    if (count == 0) return FDR_OK;
     FDR_HIP(hipSetDevice(p->device));
     hipStream_t us = (hipStream_t)stream;
-    // profiling wants clean per-kernel durations: keep everything on the caller's stream then
-    const int ns = (p->timer.enabled || count < 2) ? 1 : p->nslots;
-    if (ns == 1) {
-        for (int i = 0; i < count; ++i) {
-            int rc = wiener_dev_impl(p, p->slots[0], d_imgs + (size_t)i * img_pitch, rows, cols, stride,
-                                     d_out + (size_t)i * out_pitch, out_stride, norm_area, us);
-            if (rc != FDR_OK) return rc;
-        }
-        return FDR_OK;
+    int rc = check_image_args(p, d_imgs, rows, cols, stride, d_out, out_stride);
+    if (rc != FDR_OK) return rc;
+    const int mm_rows = norm_area == FDR_NORM_PADDED ? p->M : rows;
+    const int mm_cols = norm_area == FDR_NORM_PADDED ? p->N : cols;
+    const int group = p->panel ? p->group : 1;
+    // per-kernel profiling wants un-overlapped durations: keep everything on the caller's stream then
+    const int ns = (p->timer.enabled || count <= group) ? 1 : p->nstreams;
+    if (ns > 1) {  // fork: internal streams wait for everything queued so far on the caller's stream
+        FDR_HIP(hipEventRecord(p->fork, us));
+        for (int k = 0; k < ns; ++k) FDR_HIP(hipStreamWaitEvent(p->slots[k * group].stream, p->fork, 0));
     }
-    // fork: internal streams wait for everything queued so far on the caller's stream
-    FDR_HIP(hipEventRecord(p->fork, us));
-    for (int k = 0; k < ns; ++k) FDR_HIP(hipStreamWaitEvent(p->slots[k].stream, p->fork, 0));
-    for (int i = 0; i < count; ++i) {
-        const fdr_plan::Slot& w = p->slots[i % ns];
-        int rc = wiener_dev_impl(p, w, d_imgs + (size_t)i * img_pitch, rows, cols, stride, d_out + (size_t)i * out_pitch,
-                                 out_stride, norm_area, w.stream);
+    int chunk = 0;
+    for (int i0 = 0; i0 < count; i0 += group, ++chunk) {
+        const int n = count - i0 < group ? count - i0 : group;
+        const int sidx = chunk % ns;
+        const fdr_plan::Slot* ws[fdr_plan::kMaxSlots];
+        for (int k = 0; k < n; ++k) ws[k] = &p->slots[sidx * group + k];
+        hipStream_t s = ns > 1 ? p->slots[sidx * group].stream : us;
+        if (!p->panel) {
+            rc = wiener_dev_impl(p, *ws[0], d_imgs + (size_t)i0 * img_pitch, rows, cols, stride, d_out + (size_t)i0 * out_pitch,
+                                 out_stride, norm_area, s);
+            if (rc != FDR_OK) return rc;
+            continue;
+        }
+        for (int k = 0; k < n && rc == FDR_OK; ++k)
+            rc = panel_stage_A(p, *ws[k], d_imgs + (size_t)(i0 + k) * img_pitch, rows, cols, stride, s);
+        if (rc == FDR_OK) rc = panel_stage_B(p, ws, n, s);
+        for (int k = 0; k < n && rc == FDR_OK; ++k)
+            rc = panel_stage_CE(p, *ws[k], rows, cols, d_out + (size_t)(i0 + k) * out_pitch, out_stride, mm_rows, mm_cols, s);
         if (rc != FDR_OK) return rc;
     }
-    // join: the caller's stream continues after every internal stream has drained
-    for (int k = 0; k < ns; ++k) {
-        FDR_HIP(hipEventRecord(p->slots[k].done, p->slots[k].stream));
-        FDR_HIP(hipStreamWaitEvent(us, p->slots[k].done, 0));
+    if (ns > 1) {  // join: the caller's stream continues after every internal stream has drained
+        for (int k = 0; k < ns; ++k) {
+            FDR_HIP(hipEventRecord(p->slots[k * group].done, p->slots[k * group].stream));
+            FDR_HIP(hipStreamWaitEvent(us, p->slots[k * group].done, 0));
+        }
     }
     return FDR_OK;
 }
 
-int fdr_plan_set_concurrency(fdr_plan* p, int nstreams) {
-    if (!p) return fail(FDR_ERR_ARG, "fdr_plan_set_concurrency: null plan");
-    if (nstreams < 1 || nstreams > fdr_plan::kMaxSlots) return fail(FDR_ERR_ARG, "fdr_plan_set_concurrency: 1..4 streams");
+int fdr_plan_set_batching(fdr_plan* p, int nstreams, int group) {
+    if (!p) return fail(FDR_ERR_ARG, "fdr_plan_set_batching: null plan");
+    if (nstreams < 1 || group < 1 || group > 4 || nstreams * group > fdr_plan::kMaxSlots)
+        return fail(FDR_ERR_ARG, "fdr_plan_set_batching: need 1 <= group <= 4 and nstreams * group <= 8");
     FDR_HIP(hipSetDevice(p->device));
     if (!p->fork) FDR_HIP(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
-    for (int k = 0; k < nstreams; ++k) {
+    const int nslots = nstreams * group;
+    for (int k = 0; k < nslots; ++k) {
         fdr_plan::Slot& w = p->slots[k];
         if (!w.stream) FDR_HIP(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
         if (!w.done) FDR_HIP(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
@@ -537,12 +586,14 @@ int fdr_plan_set_concurrency(fdr_plan* p, int nstreams) {
                 hipMalloc((void**)&w.mm, 2 * sizeof(float)) != hipSuccess ||
                 hipMalloc((void**)&w.mm_part, (size_t)p->mm_part_cap * sizeof(float2)) != hipSuccess ||
                 (p->simple && hipMalloc((void**)&w.work2, p->ws_elems * sizeof(float2)) != hipSuccess))
-                return fail(FDR_ERR_ALLOC, "fdr_plan_set_concurrency: hipMalloc of an extra workspace failed");
+                return fail(FDR_ERR_ALLOC, "fdr_plan_set_batching: hipMalloc of an extra workspace failed");
         }
     }
-    p->nslots = nstreams;
+    p->nslots = nslots; p->nstreams = nstreams; p->group = group;
     return FDR_OK;
 }
+
+int fdr_plan_set_concurrency(fdr_plan* p, int nstreams) { return fdr_plan_set_batching(p, nstreams, 1); }
 
 int fdr_wiener_f32(fdr_plan* p, const float* img_host, int rows, int cols, int stride, float* out_host, int out_stride,
                    int norm_area) {
@@ -637,6 +688,24 @@ int fdr_synth_image_dev(int device, uint64_t seed, uint64_t first_index, size_t 
     FDR_HIP(hipSetDevice(device));
     FDR_HIP(launch_synth(seed, first_index, count, d_out, (hipStream_t)stream));
     return FDR_OK;
+}
+
+// debug aid (not declared in fdr.h): run passes A and B' of the fast panel path on a host image and return the
+// raw panel-major workspace (float2 count = *elems) to the host
+int fdr_debug_panel_AB(fdr_plan* p, const float* img_host, int rows, int cols, float* work_host, size_t cap_floats, size_t* elems) {
+    if (!p || !p->panel || !p->have_psf) return fail(FDR_ERR_STATE, "fdr_debug_panel_AB: needs a fast panel plan with a PSF");
+    FDR_HIP(hipSetDevice(p->device));
+    float* d_in = nullptr;
+    FDR_HIP(hipMalloc((void**)&d_in, (size_t)rows * cols * sizeof(float)));
+    FDR_HIP(hipMemcpy(d_in, img_host, (size_t)rows * cols * sizeof(float), hipMemcpyHostToDevice));
+    const fdr_plan::Slot* one[1] = {&p->slots[0]};
+    int rc = panel_stage_A(p, p->slots[0], d_in, rows, cols, cols, nullptr);
+    if (rc == FDR_OK) rc = panel_stage_B(p, one, 1, nullptr);
+    if (rc == FDR_OK && p->ws_elems * 2 <= cap_floats)
+        rc = hipMemcpy(work_host, p->work, p->ws_elems * sizeof(float2), hipMemcpyDeviceToHost) == hipSuccess ? FDR_OK : FDR_ERR_HIP;
+    if (elems) *elems = p->ws_elems;
+    (void)hipFree(d_in);
+    return rc;
 }
 
 int fdr_plan_profile(fdr_plan* p, int enable) {

@@ -33,6 +33,12 @@ struct RowArgs {
     int no_packing;     // rows4 kernels: one complex transform per row instead of two rows per transform
 };
 
+// up to 4 images' spectra handled by ONE persistent pass-B' launch (their panels form one tile sequence)
+struct PanelBatch {
+    float2* data[4];
+    int nimg;  // 0 or 1: use ColArgs::data only
+};
+
 struct ColArgs {
     float2* data;        // M x N complex, transformed in place
     const float2* filt;  // H (parity) or W (fast), M x N
@@ -42,6 +48,8 @@ struct ColArgs {
     int mm_rows, mm_cols;
     int N;  // row length (number of columns)
     int npanels;      // panel kernels: number of panels (0 = N/4)
+    PanelBatch batch; // panel kernels, COL_FUSED: several images per launch
+    int lean;         // panel kernels, COL_FUSED: single-register-set kernel, one workgroup per tile
     int packed0;      // panel kernels: column 0 of panel 0 is the packed DC + i Nyquist column (half spectrum)
     size_t pstride;   // panel kernels: panel stride in float2 elements
     int num_cu;       // CUs of the device (persistent pass B' launches one workgroup per CU)

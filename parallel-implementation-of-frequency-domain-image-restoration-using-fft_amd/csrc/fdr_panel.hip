@@ -515,11 +515,73 @@ __device__ __forceinline__ void packed_column_filter(float2 (&cur)[4][8], const 
     __syncthreads();  // both buffers were just read: the next exchange may overwrite either
 }
 
+// Tile addressing of the persistent kernel: a wave-uniform tile base (SGPRs) plus ONE 32-bit per-lane element offset
+// `loff` = (thread group's panel inside the tile) * pstride + tid * 4, so every load / store is
+// `global_* v, v_off, s[base:base+1]` and no 64-bit per-lane address lives in VGPRs.  `scale` (0 or 1, uniform)
+// collapses a prefetch onto the first 32 bytes of `ubase` when there is no next tile: the loads stay UNCONDITIONAL
+// -- a conditional prefetch makes PHIs of (loaded, old) values whose copies hipcc places right behind the loads,
+// i.e. it waits for the prefetch before the transform it was meant to hide behind (seen in the ISA as
+// `vmcnt(11) .. vmcnt(1)` directly after the 16 loads).
+template <class Core, bool OUT_ORDER>
+__device__ __forceinline__ void tile_load(const float2* __restrict__ ubase, unsigned loff, unsigned scale, float2 (&d)[4][8]) {
+    constexpr int NU = OUT_ORDER ? Core::NUL : Core::NU0, RHO = OUT_ORDER ? Core::RHOL : Core::RHO0;
+    constexpr int LOGQ = OUT_ORDER ? Core::LOGOUT : Core::LOGR0;
+    const unsigned lo = loff * scale;
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int q = 0; q < RHO; ++q) {
+            const int s = u * RHO + q;
+            const unsigned uoff = (unsigned)(((q << LOGQ) + u * Core::T) * 4) * scale;  // uniform
+#ifdef FDR_DEBUG_SKIP_MEM  // timing-only builds: pass B' without its HBM traffic
+            (void)ubase; (void)uoff;
+            d[0][s] = d[1][s] = d[2][s] = d[3][s] = make_float2(__uint_as_float(lo), 1.0f);
+#else
+            load4(ubase + uoff + lo, d[0][s], d[1][s], d[2][s], d[3][s]);
+#endif
+        }
+}
+template <class Core>
+__device__ __forceinline__ void tile_store(float2* __restrict__ ubase, unsigned loff, const float2 (&d)[4][8]) {
+#pragma unroll
+    for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+        for (int q = 0; q < Core::RHOL; ++q) {
+            const int s = u * Core::RHOL + q;
+            const unsigned uoff = (unsigned)(((q << Core::LOGOUT) + u * Core::T) * 4);
+#ifdef FDR_DEBUG_SKIP_MEM
+            if (d[0][s].x == 1.2345e-30f) store4(ubase + uoff + loff, d[0][s], d[1][s], d[2][s], d[3][s]);
+#else
+            store4(ubase + uoff + loff, d[0][s], d[1][s], d[2][s], d[3][s]);
+#endif
+        }
+}
+
+// Reads every register of a prefetched set through an empty asm, so the compiler places the wait for those loads HERE
+// and treats them as landed afterwards.  Used right before the tile's stores are issued: vmcnt counts loads and
+// stores in issue order, so a wait for the spectrum prefetch placed after the stores (where the values are first
+// used) would also wait for the stores to drain -- ~5 us per tile that the next forward transform should hide.
+__device__ __forceinline__ void landed(const float2 (&d)[4][8]) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int s = 0; s < 8; s += 4)
+            asm volatile("" ::"v"(d[b][s].x), "v"(d[b][s].y), "v"(d[b][s + 1].x), "v"(d[b][s + 1].y), "v"(d[b][s + 2].x),
+                         "v"(d[b][s + 2].y), "v"(d[b][s + 3].x), "v"(d[b][s + 3].y));
+}
+
+struct PanelTile {
+    float2* data;        // uniform: image base + first panel of the tile
+    const float2* filt;  // uniform: filter, same panel
+    unsigned loff;       // per lane: (group's panel in the tile) * pstride + tid * 4   [float2 elements]
+    int tl;              // tile index inside its image
+    bool ok;             // this thread group's panel exists (else it reads the tile's first panel and stores nothing)
+};
+
 template <int LOGM, class Core>
-__device__ __forceinline__ void panel_tile(float2 (&cur)[4][8], float2 (&flt)[4][8], float2* __restrict__ data,
-                                           const float2* __restrict__ filt, float2* grp_lds, const typename Core::Bases& bases,
-                                           const float2* __restrict__ tw_fwd, int tid, size_t poff, bool store_ok,
-                                           bool have_next, size_t next_poff, bool packed_tile, bool packed_group) {
+__device__ __forceinline__ void panel_tile(float2 (&cur)[4][8], float2 (&flt)[4][8], const PanelTile& c, const PanelTile& n,
+                                           unsigned nscale, float2* grp_lds, const typename Core::Bases& bases,
+                                           const float2* __restrict__ tw_fwd, int tid, bool packed_tile, bool packed_group) {
     Core::template run<0, false>(cur, grp_lds, tw_fwd, bases, tid);
     // column 0 of panel 0 in half-spectrum mode: uniform branch per workgroup (barriers inside); thread groups of
     // the same workgroup that hold other panels go through the same barriers and keep the plain product
@@ -535,7 +597,7 @@ __device__ __forceinline__ void panel_tile(float2 (&cur)[4][8], float2 (&flt)[4]
         cur[2][s] = cmul_fma(cur[2][s], flt[2][s]);
         cur[3][s] = cmul_fma(cur[3][s], flt[3][s]);
     }
-    if (have_next) panel_load_in<Core>(data + next_poff, tid, flt);
+    tile_load<Core, false>(n.data, n.loff, nscale, flt);  // next spectrum streams in behind the inverse transform
     constexpr int SEQ1 = Core::SLOTS;
     if constexpr (Core::RHOL != Core::RHO0) {
         redistribute<LOGM, Core, SEQ1>(cur, grp_lds, tid);
@@ -543,51 +605,65 @@ __device__ __forceinline__ void panel_tile(float2 (&cur)[4][8], float2 (&flt)[4]
     } else {
         Core::template run<SEQ1, true>(cur, grp_lds, tw_fwd, bases, tid);
     }
-    if (store_ok) panel_store_out<Core>(data + poff, tid, cur);
-    if (have_next) panel_load_out<Core>(filt + next_poff, tid, cur);
+    landed(flt);
+    if (c.ok) tile_store<Core>(c.data, c.loff, cur);
+    tile_load<Core, true>(n.filt, n.loff, nscale, cur);   // next filter streams in behind the next forward transform
 }
 
+// The tile sequence of one launch runs over the panels of up to 4 images (PanelBatch): global tile
+// t = image * ntiles + tile.  With several images per launch the un-overlapped prologue (first spectrum) and
+// epilogue (last inverse + store) of the persistent workgroups amortise over more tiles, and small images fill the chip.
 template <int LOGM>
 __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::PIPE_WAVES_PER_SIMD) void fft_cols_panel_fused_kernel(
-    float2* __restrict__ data, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const size_t pstride,
+    const PanelBatch pb, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const unsigned pstride,
     const int npanels, const int ntiles, const int packed0) {
     using St = Steps<LOGM>;
     using Geo = PanelGeom<LOGM>;
     constexpr int G = Geo::G, T = St::T;
     using Core = FftCore<LOGM, 4, 2, PolicyFast>;
     __shared__ float2 lds[G * 2 * St::BUF];
-    const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
+    // one thread group per workgroup (M >= 4096): everything about a tile except tid is wave-uniform
+    const int g = G == 1 ? 0 : (int)(threadIdx.x >> St::LOGT);
+    const int tid = threadIdx.x & (T - 1);
     float2* grp_lds = lds + g * 2 * St::BUF;
+    const int total = ntiles * pb.nimg;
     int t = blockIdx.x;
-    if (t >= ntiles) return;  // uniform over the workgroup
+    if (t >= total) return;  // uniform over the workgroup
 
     typename Core::Bases bases;
     Core::init_bases(bases, tw_fwd, tid);
 
-    auto poff_of = [&](int tile, bool& ok) {
-        const int p = tile * G + g;
-        ok = p < npanels;
-        return (size_t)(ok ? p : 0) * pstride;  // out-of-range groups read panel 0, store nothing
+    auto tile_of = [&](int gt) {
+        PanelTile r;
+        const int img = gt / ntiles;
+        r.tl = gt - img * ntiles;
+        r.ok = r.tl * G + g < npanels;
+        r.loff = (r.ok ? (unsigned)g : 0u) * pstride + (unsigned)tid * 4u;
+        const size_t tbase = (size_t)(r.tl * G) * pstride;
+        r.data = (img == 0 ? pb.data[0] : img == 1 ? pb.data[1] : img == 2 ? pb.data[2] : pb.data[3]) + tbase;
+        r.filt = filt + tbase;
+        return r;
     };
 
     float2 P[4][8], Q[4][8];
-    bool ok;
-    size_t poff = poff_of(t, ok);
-    panel_load_in<Core>(data + poff, tid, P);
-    panel_load_out<Core>(filt + poff, tid, Q);
+    PanelTile c = tile_of(t);
+    tile_load<Core, false>(c.data, c.loff, 1u, P);
+    tile_load<Core, true>(c.filt, c.loff, 1u, Q);
     while (true) {
         int tn = t + gridDim.x;
-        bool more = tn < ntiles, nok = false;
-        size_t npoff = more ? poff_of(tn, nok) : 0;
-        panel_tile<LOGM, Core>(P, Q, data, filt, grp_lds, bases, tw_fwd, tid, poff, ok, more, npoff, packed0 && t == 0, g == 0);
+        bool more = tn < total;
+        PanelTile n = tile_of(more ? tn : t);
+        if (!more) n.data = const_cast<float2*>(n.filt);  // dummy prefetch source: read-only memory
+        panel_tile<LOGM, Core>(P, Q, c, n, more ? 1u : 0u, grp_lds, bases, tw_fwd, tid, packed0 && c.tl == 0, g == 0);
         if (!more) break;
-        t = tn; poff = npoff; ok = nok;
+        t = tn; c = n;
         tn = t + gridDim.x;
-        more = tn < ntiles;
-        npoff = more ? poff_of(tn, nok) : 0;
-        panel_tile<LOGM, Core>(Q, P, data, filt, grp_lds, bases, tw_fwd, tid, poff, ok, more, npoff, packed0 && t == 0, g == 0);
+        more = tn < total;
+        n = tile_of(more ? tn : t);
+        if (!more) n.data = const_cast<float2*>(n.filt);
+        panel_tile<LOGM, Core>(Q, P, c, n, more ? 1u : 0u, grp_lds, bases, tw_fwd, tid, packed0 && c.tl == 0, g == 0);
         if (!more) break;
-        t = tn; poff = npoff; ok = nok;
+        t = tn; c = n;
     }
 }
 
@@ -599,8 +675,8 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::PIPE_WAV
 // ---------------------------------------------------------------------------------------------
 template <int LOGM>
 __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PER_SIMD) void fft_cols_panel_fused_lean_kernel(
-    float2* __restrict__ data, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const size_t pstride,
-    const int npanels, const int packed0) {
+    const PanelBatch pb, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const size_t pstride,
+    const int npanels, const int ntiles, const int packed0) {
     using St = Steps<LOGM>;
     using Geo = PanelGeom<LOGM>;
     constexpr int G = Geo::G, T = St::T, M = St::L;
@@ -608,7 +684,9 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PE
     __shared__ float2 lds[G * 2 * St::BUF];
     const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
     float2* grp_lds = lds + g * 2 * St::BUF;
-    const int p = blockIdx.x * G + g;
+    const int img = blockIdx.x / ntiles, tl = blockIdx.x - img * ntiles;
+    float2* __restrict__ data = img == 0 ? pb.data[0] : img == 1 ? pb.data[1] : img == 2 ? pb.data[2] : pb.data[3];
+    const int p = tl * G + g;
     const bool active = p < npanels;
     const size_t poff = (size_t)(active ? p : 0) * pstride;
 
@@ -619,7 +697,7 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PE
     panel_load_in<Core>(data + poff, tid, v);
     Core::template run<0, false>(v, grp_lds, tw_fwd, bases, tid);
 
-    const bool packed_tile = packed0 && blockIdx.x == 0;  // uniform per workgroup
+    const bool packed_tile = packed0 && tl == 0;  // uniform per workgroup
     constexpr int SEQ = Core::SLOTS;
     float2* bufc = grp_lds + (SEQ & 1) * St::BUF;
     float2* bufs = grp_lds + ((SEQ + 1) & 1) * St::BUF;
@@ -680,14 +758,20 @@ static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const floa
     if (kind == COL_FWD) {
         hipLaunchKernelGGL((fft_cols_panel_fwd_kernel<LOGM>), dim3(ntiles), dim3(Geo::THREADS), 0, s, a.data, tw, ps, npanels);
     } else if (kind == COL_FUSED) {
-        if constexpr (Geo::THREADS >= 1024) {  // 8192-point columns: single register set, one workgroup per panel
-            hipLaunchKernelGGL((fft_cols_panel_fused_lean_kernel<LOGM>), dim3(ntiles), dim3(Geo::THREADS), 0, s, a.data, a.filt, tw,
-                               ps, npanels, a.packed0);
+        PanelBatch pb = a.batch;
+        if (pb.nimg <= 0) { pb.nimg = 1; pb.data[0] = a.data; }
+        for (int k = pb.nimg; k < 4; ++k) pb.data[k] = pb.data[0];
+        const int total = ntiles * pb.nimg;
+        // single register set, one workgroup per tile, two workgroups per CU: always for 8192-point columns (1024
+        // threads per transform leave no room for a second set), on request (FDR_FLAG_LEAN_COLS) otherwise
+        if (Geo::THREADS >= 1024 || a.lean) {
+            hipLaunchKernelGGL((fft_cols_panel_fused_lean_kernel<LOGM>), dim3(total), dim3(Geo::THREADS), 0, s, pb, a.filt, tw,
+                               ps, npanels, ntiles, a.packed0);
             return hipGetLastError();
         }
         int grid = (a.num_cu > 0 ? a.num_cu : 256) * Geo::PIPE_WG_PER_CU;
-        if (a.no_pipeline || grid > ntiles) grid = ntiles;
-        hipLaunchKernelGGL((fft_cols_panel_fused_kernel<LOGM>), dim3(grid), dim3(Geo::THREADS), 0, s, a.data, a.filt, tw, ps,
+        if (a.no_pipeline || grid > total) grid = total;
+        hipLaunchKernelGGL((fft_cols_panel_fused_kernel<LOGM>), dim3(grid), dim3(Geo::THREADS), 0, s, pb, a.filt, tw, (unsigned)ps,
                            npanels, ntiles, a.packed0);
     } else {
         return hipErrorInvalidValue;

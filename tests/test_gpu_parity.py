@@ -187,7 +187,7 @@ def test_committed_vectors_on_gpu(fdr):
 # ------------------------------------------------------------------------------------------------
 # fast-mode variants, batched mode, large sizes
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("flags_name", ["FLAG_ROWMAJOR", "FLAG_NO_PACKING", "FLAG_NO_PIPELINE", "FLAG_POW2_PANELS", "FLAG_SIMPLE_PATH"])
+@pytest.mark.parametrize("flags_name", ["FLAG_ROWMAJOR", "FLAG_NO_PACKING", "FLAG_NO_PIPELINE", "FLAG_POW2_PANELS", "FLAG_SIMPLE_PATH", "FLAG_LEAN_COLS", "FLAG_FULL_SPECTRUM"])
 @pytest.mark.parametrize("shape", [(200, 300), (1024, 1024)])
 def test_fast_variants_within_tolerance(fdr, oracle, flags_name, shape):
     psf = oracle.motion_blur_kernel(50, 30.0)
@@ -225,6 +225,12 @@ def test_batched_multistream_equals_one_by_one(fdr, oracle, mode_name):
         p.set_concurrency(3)
         p.wiener_batch_dev(d_in.data_ptr(), rows * cols, B, rows, cols, cols, d_out3.data_ptr(), rows * cols, cols, stream=s)
         torch.cuda.synchronize()
+        for nstreams, group in ((1, 2), (2, 2), (2, 3), (1, 4)):  # several images per pass-B' launch (fast mode)
+            d_g = torch.zeros_like(d_in)
+            p.set_batching(nstreams, group)
+            p.wiener_batch_dev(d_in.data_ptr(), rows * cols, B, rows, cols, cols, d_g.data_ptr(), rows * cols, cols, stream=s)
+            torch.cuda.synchronize()
+            assert np.count_nonzero(~(d_g.cpu().numpy() == d_out1.cpu().numpy())) == 0, (nstreams, group)
         one = np.stack([p.wiener(host[i]) for i in range(B)])
     _assert_same(d_out1.cpu().numpy(), one, "batched (1 stream) vs one by one")
     _assert_same(d_out3.cpu().numpy(), one, "batched (3 streams) vs one by one")
