@@ -41,6 +41,7 @@ PASS_BYTES = {
     },
     "half": {
         "A rows: pad+FFT (real->complex)": 8, "B' cols: FFT*W*IFFT": 12, "C' rows: IFFT+real+minmax": 8, "E normalize+crop": 8,
+        "C'E rows: IFFT+minmax+normalize+crop (fused)": 8, "E' fixup (no-op unless a wait timed out)": 0,
     },
 }
 PIPELINE_BYTES = {("fast", "half"): 36, ("fast", "full"): 56, ("parity", "full"): 72}
@@ -119,6 +120,8 @@ def main():
         flags |= fdr.FLAG_FULL_SPECTRUM
     if os.environ.get("FDR_LEAN_COLS") == "1":
         flags |= fdr.FLAG_LEAN_COLS
+    if os.environ.get("FDR_FUSED_NORM") == "1":
+        flags |= fdr.FLAG_FUSED_NORM
     spectrum = "half" if (args.mode == "fast" and not (flags & fdr.FLAG_FULL_SPECTRUM) and S >= 32) else "full"
     plan = fdr.Plan(S, S, mode, device=local_rank, flags=flags)
     stream = torch.cuda.current_stream().cuda_stream
@@ -152,7 +155,9 @@ def main():
     if rank == 0:
         images = world * B * args.steps
         value = images * P / 1e6 / elapsed
-        pipe_bpp = PIPELINE_BYTES[(args.mode, spectrum)]
+        # bytes per pixel of the passes that actually ran (the fused C'E pass drops the raw-plane round trip)
+        pipe_bpp = sum(PASS_BYTES[spectrum].get(n.rsplit(" [", 1)[0] if n.endswith(" images]") else n, 0) for n, _, _ in passes) \
+            or PIPELINE_BYTES[(args.mode, spectrum)]
         pipe_gbps = pipe_bpp * P * images / elapsed / 1e9
         dom = max(passes, key=lambda t: t[1]) if passes else None  # longest launch
         roofline = None

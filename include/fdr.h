@@ -62,6 +62,13 @@ extern "C" {
                                   transforms) instead of the persistent software-pipelined kernel (A/B measurements;
                                   always used for 8192-point columns)                                              */
 
+#define FDR_FLAG_FUSED_NORM 128u /* fast mode: pass C' (rows inverse + min/max) and pass E (normalise + crop) as ONE launch
+                                    that keeps the raw plane in registers across a grid-wide min/max hand-off (-8 bytes
+                                    per pixel; images of at most 4 row groups per CU, i.e. up to 4096 x 4096 on 256 CUs).
+                                    Opt-in: a fused launch occupies every CU while it waits, so it does not overlap with
+                                    other images' passes in the batched multi-stream mode, where the two-launch form is
+                                    faster (measured: DESIGN.md section 5).                                           */
+
 /* normalisation area selector for fdr_wiener_* */
 #define FDR_NORM_PADDED 1  /* serial semantics: min/max over the padded M x N area, then crop
                               (serial.cpp:36-38 + fft/fft_serial.cpp:243-246)                 */

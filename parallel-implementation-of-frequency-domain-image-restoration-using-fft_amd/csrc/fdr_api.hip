@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -129,6 +130,8 @@ struct fdr_plan {
     struct Slot {
         float2* work = nullptr; float2* work2 = nullptr; float* raw = nullptr; float* mm = nullptr; float2* mm_part = nullptr;
         hipStream_t stream = nullptr; hipEvent_t done = nullptr;
+        // fused pass C'+E: 2 granules + 1 fallback word per workgroup, launch counter (the granule epoch)
+        unsigned long long* gran = nullptr; unsigned* fallback = nullptr; unsigned epoch = 0;
     };
     static constexpr int kMaxSlots = 8;
     Slot slots[kMaxSlots];
@@ -137,6 +140,11 @@ struct fdr_plan {
     int group = 1;    // images per pass-B' launch (panel path)
     hipEvent_t fork = nullptr;
     size_t ws_elems = 0;  // elements of one work / raw buffer
+    // fused pass C'+E (fast panel path, half spectrum, images of at most 4 row groups per CU)
+    bool fused_norm = false; int fused_R = 0, fused_nwg = 0;
+    unsigned spin_limit = 20000;     // sweeps (~0.5 us each) before a waiting workgroup falls back
+    hipEvent_t fused_done = nullptr; // fused launches of one plan never overlap: each holds every CU while it waits
+    bool fused_recorded = false;
 };
 
 namespace {
@@ -165,6 +173,8 @@ const char* const kPassColsFusedN[5] = {nullptr, kPassColsFused, "B' cols: FFT*W
                                        "B' cols: FFT*W*IFFT [4 images]"};
 const char* const kPassRowsInvReal = "C' rows: IFFT+real+minmax";
 const char* const kPassNormalize = "E normalize+crop";
+const char* const kPassRowsInvNorm = "C'E rows: IFFT+minmax+normalize+crop (fused)";
+const char* const kPassFixup = "E' fixup (no-op unless a wait timed out)";
 const char* const kPassSimple = "simple path (reference-shaped)";
 
 int upload(float2** dst, const std::vector<float2>& v) {
@@ -231,8 +241,23 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
     return FDR_OK;
 }
 
+#ifdef FDR_DEBUG_STAMPS
+unsigned long long* g_debug_stamps = nullptr;
+#endif
+
+int ensure_fused_sync(fdr_plan* p, fdr_plan::Slot& w) {
+    if (w.gran) return FDR_OK;
+    const size_t n = (size_t)p->fused_nwg;
+    FDR_HIP(hipMalloc((void**)&w.gran, 2 * n * sizeof(unsigned long long)));
+    FDR_HIP(hipMalloc((void**)&w.fallback, n * sizeof(unsigned)));
+    FDR_HIP(hipMemset(w.gran, 0, 2 * n * sizeof(unsigned long long)));  // epoch 0 never matches a launch
+    FDR_HIP(hipMemset(w.fallback, 0, n * sizeof(unsigned)));
+    w.epoch = 0;
+    return FDR_OK;
+}
+
 // ---- fast panel path in three stages, so that pass B' can be launched once for a group of images ----
-int panel_stage_A(fdr_plan* p, const fdr_plan::Slot& w, const float* d_img, int rows, int cols, int stride, hipStream_t s) {
+int panel_stage_A(fdr_plan* p, fdr_plan::Slot& w, const float* d_img, int rows, int cols, int stride, hipStream_t s) {
     ScopedPass t(p, s, kPassRowsFwd);   // A: 4 rows per thread group, real -> panel-major (half) spectrum
     RowArgs a{};
     a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
@@ -240,7 +265,7 @@ int panel_stage_A(fdr_plan* p, const fdr_plan::Slot& w, const float* d_img, int 
     FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
     return FDR_OK;
 }
-int panel_stage_B(fdr_plan* p, const fdr_plan::Slot* const* ws, int n, hipStream_t s) {
+int panel_stage_B(fdr_plan* p, fdr_plan::Slot* const* ws, int n, hipStream_t s) {
     ScopedPass t(p, s, kPassColsFusedN[n]);  // B': per panel, columns forward * W * inverse, persistent + double-buffered
     ColArgs c{};
     c.data = ws[0]->work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu; c.no_pipeline = p->no_pipeline;
@@ -251,8 +276,40 @@ int panel_stage_B(fdr_plan* p, const fdr_plan::Slot* const* ws, int n, hipStream
     FDR_HIP(launch_cols_panel(p->logM, COL_FUSED, c, p->tw_col_f, s));
     return FDR_OK;
 }
-int panel_stage_CE(fdr_plan* p, const fdr_plan::Slot& w, int rows, int cols, float* d_out, int out_stride, int mm_rows,
+int panel_stage_CE(fdr_plan* p, fdr_plan::Slot& w, int rows, int cols, float* d_out, int out_stride, int mm_rows,
                    int mm_cols, hipStream_t s) {
+    if (p->fused_norm) {  // C'+E in one launch: the raw plane stays in registers across a granule hand-off
+        int rc = ensure_fused_sync(p, w);
+        if (rc != FDR_OK) return rc;
+        RowArgs a{};
+        a.src_c = w.work; a.dst_real = w.raw; a.mm_part = w.mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
+        a.pstride = p->pstride; a.half = 1;
+        NormArgs na{};
+        if (++w.epoch == 0) w.epoch = 1;
+        na.gran = w.gran; na.fallback = w.fallback; na.epoch = w.epoch; na.spin_limit = p->spin_limit;
+        na.out = d_out; na.rows = rows; na.cols = cols; na.out_stride = out_stride;
+#ifdef FDR_DEBUG_STAMPS
+        {   // timing-only builds: one pinned buffer per process, dumped by fdr_debug_dump_stamps
+            static unsigned long long* g_stamps = nullptr;
+            if (!g_stamps) { (void)hipHostMalloc((void**)&g_stamps, 1024 * 32 * sizeof(unsigned long long)); memset(g_stamps, 0, 1024 * 32 * 8); g_debug_stamps = g_stamps; }
+            na.stamps = g_stamps;
+        }
+#endif
+        {
+            ScopedPass t(p, s, kPassRowsInvNorm);
+            // every workgroup of a fused launch holds its CU until all of them have published: two such launches must
+            // not share the chip (streams of the batched mode), so each waits for the previous one of this plan
+            if (p->fused_recorded) FDR_HIP(hipStreamWaitEvent(s, p->fused_done, 0));
+            FDR_HIP(launch_rows4_inv_norm(p->logN, p->fused_R, p->fused_nwg, a, na, p->tw_row_f, s));
+            FDR_HIP(hipEventRecord(p->fused_done, s));
+            p->fused_recorded = true;
+        }
+        {
+            ScopedPass t(p, s, kPassFixup);
+            FDR_HIP(launch_normalize_fixup(p->logN, p->fused_R, p->fused_nwg, a, na, s));
+        }
+        return FDR_OK;
+    }
     {   // C': 4 rows rebuilt from the panels, inverse, real plane, min/max partials
         ScopedPass t(p, s, kPassRowsInvReal);
         RowArgs a{};
@@ -277,7 +334,7 @@ int check_image_args(fdr_plan* p, const float* d_img, int rows, int cols, int st
     return FDR_OK;
 }
 
-int wiener_dev_impl(fdr_plan* p, const fdr_plan::Slot& w, const float* d_img, int rows, int cols, int stride, float* d_out,
+int wiener_dev_impl(fdr_plan* p, fdr_plan::Slot& w, const float* d_img, int rows, int cols, int stride, float* d_out,
                     int out_stride, int norm_area, hipStream_t s) {
     int vrc = check_image_args(p, d_img, rows, cols, stride, d_out, out_stride);
     if (vrc != FDR_OK) return vrc;
@@ -323,7 +380,7 @@ int wiener_dev_impl(fdr_plan* p, const fdr_plan::Slot& w, const float* d_img, in
             n_part = cols_minmax_partials(p->logM, p->N);
         }
     } else if (p->panel) {
-        const fdr_plan::Slot* one[1] = {&w};
+        fdr_plan::Slot* one[1] = {&w};
         int rc = panel_stage_A(p, w, d_img, rows, cols, stride, s);
         if (rc == FDR_OK) rc = panel_stage_B(p, one, 1, s);
         if (rc == FDR_OK) rc = panel_stage_CE(p, w, rows, cols, d_out, out_stride, mm_rows, mm_cols, s);
@@ -413,6 +470,9 @@ int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan
         p->half = !p->no_packing && N >= 32 && (flags & FDR_FLAG_FULL_SPECTRUM) == 0;
         p->npanels = p->half ? N / 8 : N / 4;
         P = (size_t)p->npanels * p->pstride;
+        p->fused_norm = p->half && (flags & FDR_FLAG_FUSED_NORM) != 0 &&
+                        rows4_fused_geometry(p->logN, M, p->num_cu, &p->fused_R, &p->fused_nwg) != 0;
+        if (const char* e = getenv("FDR_DEBUG_SPIN_LIMIT")) p->spin_limit = (unsigned)strtoul(e, nullptr, 10);  // tests: force the fallback
     }
     std::vector<float2> t;
     int rc = FDR_OK;
@@ -427,6 +487,10 @@ int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan
         hipMalloc((void**)&p->mm_part, (size_t)(p->mm_part_cap = (int)(((size_t)N + 255) / 256 * M + 8192)) * sizeof(float2)) != hipSuccess ||
         (p->simple && hipMalloc((void**)&p->work2, P * sizeof(float2)) != hipSuccess)) {
         rc = fail(FDR_ERR_ALLOC, "fdr_plan_create: hipMalloc of the plan workspace failed");
+        goto bad;
+    }
+    if (p->fused_norm && hipEventCreateWithFlags(&p->fused_done, hipEventDisableTiming) != hipSuccess) {
+        rc = fail(FDR_ERR_HIP, "fdr_plan_create: hipEventCreate failed");
         goto bad;
     }
     p->ws_elems = P;
@@ -450,8 +514,10 @@ int fdr_plan_destroy(fdr_plan* p) {
     for (int k = 0; k < fdr_plan::kMaxSlots; ++k) {
         if (p->slots[k].stream) (void)hipStreamDestroy(p->slots[k].stream);
         if (p->slots[k].done) (void)hipEventDestroy(p->slots[k].done);
+        (void)hipFree(p->slots[k].gran); (void)hipFree(p->slots[k].fallback);
     }
     if (p->fork) (void)hipEventDestroy(p->fork);
+    if (p->fused_done) (void)hipEventDestroy(p->fused_done);
     (void)hipFree(p->tw_row_f); (void)hipFree(p->tw_row_i); (void)hipFree(p->tw_col_f); (void)hipFree(p->tw_col_i);
     (void)hipFree(p->work); (void)hipFree(p->work2); (void)hipFree(p->filt); (void)hipFree(p->raw);
     (void)hipFree(p->psf_dev); (void)hipFree(p->mm); (void)hipFree(p->mm_part);
@@ -544,7 +610,7 @@ int fdr_wiener_batch_f32_dev(fdr_plan* p, const float* d_imgs, size_t img_pitch,
     for (int i0 = 0; i0 < count; i0 += group, ++chunk) {
         const int n = count - i0 < group ? count - i0 : group;
         const int sidx = chunk % ns;
-        const fdr_plan::Slot* ws[fdr_plan::kMaxSlots];
+        fdr_plan::Slot* ws[fdr_plan::kMaxSlots];
         for (int k = 0; k < n; ++k) ws[k] = &p->slots[sidx * group + k];
         hipStream_t s = ns > 1 ? p->slots[sidx * group].stream : us;
         if (!p->panel) {
@@ -690,23 +756,15 @@ int fdr_synth_image_dev(int device, uint64_t seed, uint64_t first_index, size_t 
     return FDR_OK;
 }
 
-// debug aid (not declared in fdr.h): run passes A and B' of the fast panel path on a host image and return the
-// raw panel-major workspace (float2 count = *elems) to the host
-int fdr_debug_panel_AB(fdr_plan* p, const float* img_host, int rows, int cols, float* work_host, size_t cap_floats, size_t* elems) {
-    if (!p || !p->panel || !p->have_psf) return fail(FDR_ERR_STATE, "fdr_debug_panel_AB: needs a fast panel plan with a PSF");
-    FDR_HIP(hipSetDevice(p->device));
-    float* d_in = nullptr;
-    FDR_HIP(hipMalloc((void**)&d_in, (size_t)rows * cols * sizeof(float)));
-    FDR_HIP(hipMemcpy(d_in, img_host, (size_t)rows * cols * sizeof(float), hipMemcpyHostToDevice));
-    const fdr_plan::Slot* one[1] = {&p->slots[0]};
-    int rc = panel_stage_A(p, p->slots[0], d_in, rows, cols, cols, nullptr);
-    if (rc == FDR_OK) rc = panel_stage_B(p, one, 1, nullptr);
-    if (rc == FDR_OK && p->ws_elems * 2 <= cap_floats)
-        rc = hipMemcpy(work_host, p->work, p->ws_elems * sizeof(float2), hipMemcpyDeviceToHost) == hipSuccess ? FDR_OK : FDR_ERR_HIP;
-    if (elems) *elems = p->ws_elems;
-    (void)hipFree(d_in);
-    return rc;
+#ifdef FDR_DEBUG_STAMPS
+// timing-only builds, not part of fdr.h: copies the last fused launch's per-workgroup stamps (32 words each)
+int fdr_debug_dump_stamps(unsigned long long* dst, int nwg) {
+    if (!g_debug_stamps) return FDR_ERR_STATE;
+    (void)hipDeviceSynchronize();
+    memcpy(dst, g_debug_stamps, (size_t)nwg * 32 * sizeof(unsigned long long));
+    return FDR_OK;
 }
+#endif
 
 int fdr_plan_profile(fdr_plan* p, int enable) {
     if (!p) return fail(FDR_ERR_ARG, "fdr_plan_profile: null plan");

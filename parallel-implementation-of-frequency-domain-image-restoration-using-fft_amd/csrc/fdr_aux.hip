@@ -236,13 +236,6 @@ hipError_t launch_reduce_minmax(const float2* mm_part, int n_part, float* mm, hi
 // float, shift = (float)dmin - (float)(smin*scale); applied as a float multiply then a float add.
 // Every workgroup first folds the (few thousand) per-workgroup min/max partials itself -- a fixed
 // order, so the result is deterministic -- which saves a separate reduce launch (~4.4 us).
-__device__ __forceinline__ void minmax_to_scale_shift(float mn, float mx, float& fscale, float& fshift) {
-    const double smin = (double)mn, smax = (double)mx;
-    double scale = ((smax - smin) > 2.2204460492503131e-16) ? 1.0 / (smax - smin) : 0.0;
-    scale = (double)(float)scale;
-    fscale = (float)scale;
-    fshift = 0.0f - (float)(smin * scale);
-}
 
 template <bool VEC4>
 __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ raw, int N, const float2* __restrict__ part,

@@ -308,4 +308,14 @@ __device__ __forceinline__ void block_minmax_store(float mn, float mx, float2* _
     }
 }
 
+// cv::normalize(src, dst, 0, 1, NORM_MINMAX) scale / shift (fft/fft_serial.cpp:246): double min/max, scale rounded to
+// float, shift = (float)0 - (float)(smin * scale); applied as a float multiply then a float add.
+__device__ __forceinline__ void minmax_to_scale_shift(float mn, float mx, float& fscale, float& fshift) {
+    const double smin = (double)mn, smax = (double)mx;
+    double scale = ((smax - smin) > 2.2204460492503131e-16) ? 1.0 / (smax - smin) : 0.0;
+    scale = (double)(float)scale;
+    fscale = (float)scale;
+    fshift = 0.0f - (float)(smin * scale);
+}
+
 }  // namespace fdr

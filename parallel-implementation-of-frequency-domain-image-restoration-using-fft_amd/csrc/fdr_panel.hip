@@ -256,6 +256,90 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
     }
 }
 
+// Four Hermitian row spectra (rows rr .. rr+3) rebuilt from the panel-major (half) spectrum and packed two rows per
+// complex transform, in two steps so that the loads of the NEXT row group can be issued (into y) before the values
+// are touched:  rows4_load_raw -> y[row][slot] (first-step operand order, stored column of slot s),
+//               rows4_pack     -> z[0] = Y_a + i Y_b (rows rr, rr+1), z[1] = rows rr+2, rr+3.
+//
+// Instruction count matters here (a VALU instruction costs 4 cycles per wave, and these kernels run 2 waves per SIMD):
+// which half of the spectrum a slot lies in is a compile-time property of its q (n = tid + u T + q 2^LOGR0, and
+// q >= RHO0/2  <=>  n >= L/2), so the mirrored slots (n > L/2: stored column L-n, conjugated) need no per-lane
+// selects; only lane tid = 0 differs (n = 0: DC, n = L/2: Nyquist -- both live in the packed column 0) and is
+// patched separately.  Addresses: one uniform base per slot + two per-lane 32-bit offsets (direct / mirrored).
+template <int LOGL, bool HALF, class Core>
+__device__ __forceinline__ void rows4_load_raw(const RowArgs& a, int rr, int tid, float2 (&y)[4][8]) {
+    constexpr int L = Steps<LOGL>::L;
+    if constexpr (!HALF || LOGL < 5) {  // (half-spectrum plans need N >= 32; smaller instantiations are never launched)
+#pragma unroll
+        for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+            for (int q = 0; q < Core::RHO0; ++q) {
+                const int s = u * Core::RHO0 + q;
+                const int n = Core::in_index(tid, u, q);
+                const float2* p = a.src_c + (size_t)(n >> 2) * a.pstride + (size_t)rr * 4 + (n & 3);
+                y[0][s] = p[0]; y[1][s] = p[4]; y[2][s] = p[8]; y[3][s] = p[12];
+            }
+    } else {
+        static_assert(Core::RHO0 >= 2 && Core::LOGR0 >= 2, "n = t + q Q with Q a multiple of 4");
+        const unsigned ps = (unsigned)a.pstride;
+#pragma unroll
+        for (int u = 0; u < Core::NU0; ++u) {
+            const unsigned t = (unsigned)(tid + u * Core::T);        // n = t + q Q,  Q = 2^LOGR0 (a multiple of 4)
+            const unsigned ta = t >> 2, tb = t & 3u;
+            // direct half: stored column t + qQ -> panel qQ/4 + ta, column tb
+            const unsigned off_d = ta * ps + tb + (unsigned)rr * 4u;
+            // mirrored half: stored column (RHO0 - q) Q - t -> panel (RHO0-q)Q/4 - ta - (tb != 0), column (4 - tb) & 3;
+            // relative to q = RHO0/2 (panel L/8): the lane part is folded into an offset from panel (L/8 - T NU0/4 ... ) >= 0
+            constexpr unsigned PMID = (unsigned)(L / 8);              // panel of column L/2 (one past the stored panels)
+            const unsigned pm = PMID - ta - (tb != 0u ? 1u : 0u);     // panel of the mirrored column at q = RHO0/2
+            const unsigned off_m = pm * ps + ((4u - tb) & 3u) + (unsigned)rr * 4u;
+            // n = L/2 (lane t = 0 of the q = RHO0/2 slot): the Nyquist value rides in column 0 of panel 0
+            const unsigned off_n = (u == 0 && t == 0u) ? (unsigned)rr * 4u : off_m;
+#pragma unroll
+            for (int q = 0; q < Core::RHO0; ++q) {
+                const int s = u * Core::RHO0 + q;
+#ifdef FDR_DEBUG_SKIP_MEM  // timing-only builds
+                y[0][s] = y[1][s] = y[2][s] = y[3][s] = make_float2((float)(off_d + q), (float)(off_m + off_n));
+#else
+                const float2* p;
+                if (q < Core::RHO0 / 2) {
+                    p = a.src_c + (size_t)((q << Core::LOGR0) >> 2) * ps + off_d;
+                } else if (q == Core::RHO0 / 2) {
+                    p = a.src_c + off_n;
+                } else {  // (RHO0 - q) Q = L/2 - (q - RHO0/2) Q: uniform step back from the q = RHO0/2 panel
+                    p = a.src_c - (size_t)(((q - Core::RHO0 / 2) << Core::LOGR0) >> 2) * ps + off_m;
+                }
+                y[0][s] = p[0]; y[1][s] = p[4]; y[2][s] = p[8]; y[3][s] = p[12];
+#endif
+            }
+        }
+    }
+}
+template <int LOGL, bool HALF, class Core>
+__device__ __forceinline__ void rows4_pack(int tid, const float2 (&y)[4][8], float2 (&z)[2][8]) {
+#pragma unroll
+    for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+        for (int q = 0; q < Core::RHO0; ++q) {
+            const int s = u * Core::RHO0 + q;
+            const float2 y0 = y[0][s], y1 = y[1][s], y2 = y[2][s], y3 = y[3][s];
+            if (HALF && LOGL >= 5 && q >= Core::RHO0 / 2) {  // mirrored column: conjugate, then Y_a + i Y_b
+                z[0][s] = make_float2(y0.x + y1.y, y1.x - y0.y);
+                z[1][s] = make_float2(y2.x + y3.y, y3.x - y2.y);
+            } else {
+                z[0][s] = make_float2(y0.x - y1.y, y0.y + y1.x);  // Y_a + i Y_b
+                z[1][s] = make_float2(y2.x - y3.y, y2.y + y3.x);
+            }
+        }
+    if (HALF && LOGL >= 5 && tid == 0) {  // n = 0 (DC) and n = L/2 (Nyquist): real values packed as (DC, Nyquist) in column 0
+        constexpr int SN = Core::RHO0 / 2;  // slot of n = L/2 (u = 0)
+        z[0][0] = make_float2(y[0][0].x, y[1][0].x);
+        z[1][0] = make_float2(y[2][0].x, y[3][0].x);
+        z[0][SN] = make_float2(y[0][SN].y, y[1][SN].y);
+        z[1][SN] = make_float2(y[2][SN].y, y[3][SN].y);
+    }
+}
+
 // HALF: the row spectra hold columns 0 .. N/2-1 only, column 0 packed as Y[m,0] + i Y[m,N/2] (see the forward
 // kernel); the upper half is rebuilt on load as the conjugate of the mirrored column (every stored line is
 // touched twice by the same workgroup, the second time from L1/L2).
@@ -277,54 +361,295 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_pa
     Core::init_bases(bases, tw_fwd, tid);
 
     float2 z[2][8];
-#pragma unroll
-    for (int u = 0; u < Core::NU0; ++u)
-#pragma unroll
-        for (int q = 0; q < Core::RHO0; ++q) {
-            const int s = u * Core::RHO0 + q;
-            const int n = Core::in_index(tid, u, q);
-            int pidx = n >> 2, cidx = n & 3;
-            float sgn = 1.0f;
-            if (HALF) {
-                const int m = n <= L / 2 ? n : L - n;  // stored column
-                sgn = n > L / 2 ? -1.0f : 1.0f;        // conjugate for the mirrored half
-                pidx = m == L / 2 ? 0 : (m >> 2);
-                cidx = m == L / 2 ? 0 : (m & 3);
-            }
-            const float2* p = a.src_c + (size_t)pidx * a.pstride + (size_t)rr * 4 + cidx;
-            float2 y0 = p[0], y1 = p[4], y2 = p[8], y3 = p[12];
-            if (HALF) {
-                const int m = n <= L / 2 ? n : L - n;
-                if (m == L / 2) { y0.x = y0.y; y1.x = y1.y; y2.x = y2.y; y3.x = y3.y; }      // Nyquist: imaginary part of the packed column
-                if (m == 0 || m == L / 2) { y0.y = 0.f; y1.y = 0.f; y2.y = 0.f; y3.y = 0.f; }  // both are real
-            }
-            y0.y *= sgn; y1.y *= sgn; y2.y *= sgn; y3.y *= sgn;
-            z[0][s] = make_float2(y0.x - y1.y, y0.y + y1.x);  // Y_a + i Y_b
-            z[1][s] = make_float2(y2.x - y3.y, y2.y + y3.x);
-        }
+    {
+        float2 y[4][8];
+        rows4_load_raw<LOGL, HALF, Core>(a, rr, tid, y);
+        rows4_pack<LOGL, HALF, Core>(tid, y, z);
+    }
 
     Core::template run<0, true>(z, lds + g * 2 * St::BUF, tw_fwd, bases, tid);
 
     float mn = __builtin_inff(), mx = -__builtin_inff();
     if (active) {
+        // four row bases + the lane's column: the stores need no per-element 64-bit address arithmetic
+        float* o0 = a.dst_real + (size_t)r0 * L + tid;
+        float* o1 = o0 + L;
+        float* o2 = o1 + L;
+        float* o3 = o2 + L;
+#pragma unroll
+        for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+            for (int q = 0; q < Core::RHOL; ++q) {
+                const int s = u * Core::RHOL + q;
+                const int c = u * T + (q << Core::LOGOUT);
+                o0[c] = z[0][s].x; o1[c] = z[0][s].y; o2[c] = z[1][s].x; o3[c] = z[1][s].y;
+            }
+        if (r0 + 3 < a.mm_rows && a.mm_cols >= L) {  // whole group counted (always, with FDR_NORM_PADDED)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                mn = fminf(fminf(mn, z[0][s].x), fminf(z[0][s].y, fminf(z[1][s].x, z[1][s].y)));
+                mx = fmaxf(fmaxf(mx, z[0][s].x), fmaxf(z[0][s].y, fmaxf(z[1][s].x, z[1][s].y)));
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int s = u * Core::RHOL + q;
+                    const int n = Core::out_index(tid, u, q);
+                    const float r[4] = {z[0][s].x, z[0][s].y, z[1][s].x, z[1][s].y};
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (r0 + b < a.mm_rows && n < a.mm_cols) {
+                            mn = fminf(mn, r[b]);
+                            mx = fmaxf(mx, r[b]);
+                        }
+                }
+        }
+    }
+    block_minmax_store(mn, mx, a.mm_part);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused pass C'+E (see NormArgs in fdr_kernels.hpp).  Thread group g of workgroup w owns the 4-row groups
+//   gi(r) = (r * nwg + w) * G + g,  r = 0 .. R-1
+// (round-robin over workgroups, so at any time the chip reads one contiguous band of rows).  The R results stay
+// in registers (32 floats per group and thread); the raw spectrum of group r+1 is requested before group r is
+// transformed and lands behind it.  Straight-line code (R is a template parameter): no loop-carried registers.
+// ---------------------------------------------------------------------------------------------
+#ifdef FDR_DEBUG_STAMPS  // timing-only builds: per-workgroup timeline of the fused kernel (100 MHz clock), own buffer
+#define FDR_STAMP(args, w, k) do { if (threadIdx.x == 0 && (args).stamps) (args).stamps[(size_t)(w) * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FDR_STAMP(args, w, k) do { } while (0)
+#endif
+
+// round r of fft_rows4_inv_norm_kernel (compile-time recursion: the LDS slot sequence of the core is a template argument)
+template <int LOGL, int R, int r>
+__device__ __forceinline__ void fused_round(const RowArgs& a, const float2* __restrict__ tw_fwd,
+                                            const typename FftCore<LOGL, 2, 2, PolicyFast>::Bases& bases, float2* grp_lds, int tid,
+                                            int g, int w, int nwg, float2 (&y)[4][8], float2 (&zk)[R][2][8], float& mn, float& mx,
+                                            const NormArgs& na) {
+    using Core = FftCore<LOGL, 2, 2, PolicyFast>;
+    constexpr int G = Rows4PackGeom<LOGL>::G;
+    const int M = a.M;
+    const int r0 = ((r * nwg + w) * G + g) * 4;
+    rows4_pack<LOGL, true, Core>(tid, y, zk[r]);
+    FDR_STAMP(na, w, 8 + 4 * r);
+    if constexpr (r + 1 < R) {
+        const int r1 = (((r + 1) * nwg + w) * G + g) * 4;
+        rows4_load_raw<LOGL, true, Core>(a, r1 < M ? r1 : 0, tid, y);  // inactive groups read rows 0..3, count and store nothing
+    }
+    FDR_STAMP(na, w, 9 + 4 * r);
+    Core::template run<r * Core::SLOTS, true>(zk[r], grp_lds, tw_fwd, bases, tid);
+    FDR_STAMP(na, w, 10 + 4 * r);
+    if (r0 < M) {
+        if (r0 + 3 < a.mm_rows && a.mm_cols >= Steps<LOGL>::L) {  // whole group counted (always, with NORM_PADDED)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                mn = fminf(fminf(mn, zk[r][0][s].x), fminf(zk[r][0][s].y, fminf(zk[r][1][s].x, zk[r][1][s].y)));
+                mx = fmaxf(fmaxf(mx, zk[r][0][s].x), fmaxf(zk[r][0][s].y, fmaxf(zk[r][1][s].x, zk[r][1][s].y)));
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int s = u * Core::RHOL + q;
+                    const int n = Core::out_index(tid, u, q);
+                    const float v4[4] = {zk[r][0][s].x, zk[r][0][s].y, zk[r][1][s].x, zk[r][1][s].y};
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (r0 + b < a.mm_rows && n < a.mm_cols) {
+                            mn = fminf(mn, v4[b]);
+                            mx = fmaxf(mx, v4[b]);
+                        }
+                }
+        }
+    }
+    FDR_STAMP(na, w, 11 + 4 * r);
+    if constexpr (r + 1 < R) fused_round<LOGL, R, r + 1>(a, tw_fwd, bases, grp_lds, tid, g, w, nwg, y, zk, mn, mx, na);
+}
+
+template <int LOGL, int R>
+__global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_norm_kernel(const RowArgs a, const NormArgs na,
+                                                                                        const float2* __restrict__ tw_fwd) {
+    using St = Steps<LOGL>;
+    using Geo = Rows4PackGeom<LOGL>;
+    constexpr int G = Geo::G, T = St::T, L = St::L;
+    using Core = FftCore<LOGL, 2, 2, PolicyFast>;
+    __shared__ float2 lds[G * 2 * St::BUF];
+    __shared__ float2 red[16];
+    __shared__ float res[4];
+    const int g = G == 1 ? 0 : (int)(threadIdx.x >> St::LOGT);
+    const int tid = threadIdx.x & (T - 1);
+    const int M = a.M;
+    const int nwg = gridDim.x, w = blockIdx.x;
+
+    typename Core::Bases bases;
+    Core::init_bases(bases, tw_fwd, tid);
+
+    float2 zk[R][2][8];  // results: zk[r][0][s] = (row 0, row 1), zk[r][1][s] = (row 2, row 3) of group r at column out_index(s)
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    float2 y[4][8];
+    {
+        const int r0 = (w * G + g) * 4;
+        rows4_load_raw<LOGL, true, Core>(a, r0 < M ? r0 : 0, tid, y);
+    }
+    FDR_STAMP(na, w, 0);
+    fused_round<LOGL, R, 0>(a, tw_fwd, bases, lds + g * 2 * St::BUF, tid, g, w, nwg, y, zk, mn, mx, na);
+    FDR_STAMP(na, w, 1);
+
+    // workgroup min / max -> thread 0
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, off));
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+    }
+    const int wave = threadIdx.x >> 6, nwaves = (Geo::THREADS + 63) >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) red[wave] = make_float2(mn, mx);
+    __syncthreads();
+    if (wave == 0) {
+        if (lane == 0) {
+            for (int k = 1; k < nwaves; ++k) {
+                mn = fminf(mn, red[k].x);
+                mx = fmaxf(mx, red[k].y);
+            }
+            // publish: the value IS the flag -- one 8-byte {epoch, bits} granule each, agent-scope (write-through) stores
+            __hip_atomic_store(na.gran + 2 * w, ((unsigned long long)na.epoch << 32) | __float_as_uint(mn), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(na.gran + 2 * w + 1, ((unsigned long long)na.epoch << 32) | __float_as_uint(mx), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            res[2] = mn; res[3] = mx;  // own partial, for the fallback path
+        }
+        FDR_STAMP(na, w, 2);
+        // sweep all 2 * nwg granules until every tag carries this launch's epoch (bounded)
+        float gmn, gmx;
+        bool timed_out = false;
+        for (unsigned spins = 0;; ++spins) {
+            bool ok = true;
+            gmn = __builtin_inff(); gmx = -__builtin_inff();
+            for (int i = lane; i < 2 * nwg; i += 64) {
+                const unsigned long long x = __hip_atomic_load(na.gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && (unsigned)(x >> 32) == na.epoch;
+                const float v = __uint_as_float((unsigned)x);
+                if (i & 1) gmx = fmaxf(gmx, v); else gmn = fminf(gmn, v);
+            }
+            if (__all(ok)) break;
+            if (spins >= na.spin_limit) { timed_out = true; break; }  // uniform over the wave
+            __builtin_amdgcn_s_sleep(16);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            gmn = fminf(gmn, __shfl_xor(gmn, off));
+            gmx = fmaxf(gmx, __shfl_xor(gmx, off));
+        }
+        if (lane == 0) { res[0] = timed_out ? 1.0f : 0.0f; if (!timed_out) { res[2] = gmn; res[3] = gmx; } }
+    }
+    __syncthreads();
+    FDR_STAMP(na, w, 3);
+    const bool fallback = res[0] != 0.0f;
+    float fscale = 1.0f, fshift = 0.0f;
+    if (!fallback) minmax_to_scale_shift(res[2], res[3], fscale, fshift);
+    else if (threadIdx.x == 0) {
+        a.mm_part[w] = make_float2(res[2], res[3]);
+        na.fallback[w] = 1u;
+    }
+
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int r0 = ((r * nwg + w) * G + g) * 4;
+        if (r0 >= M) continue;
+        if (!fallback && r0 + 3 < na.rows && na.cols >= L) {
+            // common case, no crop inside this group: four row bases (uniform when G == 1) + the lane's column
+            float* o0 = na.out + (size_t)r0 * na.out_stride + tid;
+            float* o1 = o0 + na.out_stride;
+            float* o2 = o1 + na.out_stride;
+            float* o3 = o2 + na.out_stride;
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int s = u * Core::RHOL + q;
+                    constexpr int dummy = 0; (void)dummy;
+                    const int c = u * T + (q << Core::LOGOUT);
+#ifdef FDR_DEBUG_SKIP_MEM
+                    if (zk[r][0][s].x != 1.2345e-30f) continue;
+#endif
+                    const float p0 = zk[r][0][s].x * fscale, p1 = zk[r][0][s].y * fscale;
+                    const float p2 = zk[r][1][s].x * fscale, p3 = zk[r][1][s].y * fscale;
+                    o0[c] = p0 + fshift; o1[c] = p1 + fshift; o2[c] = p2 + fshift; o3[c] = p3 + fshift;
+                }
+            continue;
+        }
 #pragma unroll
         for (int u = 0; u < Core::NUL; ++u)
 #pragma unroll
             for (int q = 0; q < Core::RHOL; ++q) {
                 const int s = u * Core::RHOL + q;
                 const int n = Core::out_index(tid, u, q);
-                const float r[4] = {z[0][s].x, z[0][s].y, z[1][s].x, z[1][s].y};
+                const float v4[4] = {zk[r][0][s].x, zk[r][0][s].y, zk[r][1][s].x, zk[r][1][s].y};
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    a.dst_real[(size_t)(r0 + b) * L + n] = r[b];
-                    if (r0 + b < a.mm_rows && n < a.mm_cols) {
-                        mn = fminf(mn, r[b]);
-                        mx = fmaxf(mx, r[b]);
+                    if (fallback) {
+                        a.dst_real[(size_t)(r0 + b) * L + n] = v4[b];
+#ifdef FDR_DEBUG_SKIP_MEM
+                    } else if (r0 + b < na.rows && n < na.cols && v4[b] == 1.2345e-30f) {
+#else
+                    } else if (r0 + b < na.rows && n < na.cols) {
+#endif
+                        const float p = v4[b] * fscale;
+                        na.out[(size_t)(r0 + b) * na.out_stride + n] = p + fshift;
                     }
                 }
             }
     }
-    block_minmax_store(mn, mx, a.mm_part);
+    FDR_STAMP(na, w, 4);
+#ifdef FDR_DEBUG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FDR_STAMP(na, w, 5);
+#endif
+}
+
+// Repairs the rows of workgroups whose wait timed out in fft_rows4_inv_norm_kernel (normally none: every workgroup
+// returns after reading one word).  Same grid; by now every granule of this epoch is in memory.
+template <int LOGL, int R>
+__global__ __launch_bounds__(256) void normalize_fixup_kernel(const RowArgs a, const NormArgs na) {
+    using Geo = Rows4PackGeom<LOGL>;
+    constexpr int G = Geo::G, L = Steps<LOGL>::L;
+    const int w = blockIdx.x, nwg = gridDim.x;
+    if (na.fallback[w] == 0u) return;  // uniform
+    __shared__ float2 red[4];
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    for (int i = threadIdx.x; i < 2 * nwg; i += 256) {
+        const unsigned long long x = __hip_atomic_load(na.gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float v = __uint_as_float((unsigned)x);
+        if (i & 1) mx = fmaxf(mx, v); else mn = fminf(mn, v);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, off));
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = make_float2(mn, mx);
+    __syncthreads();
+    mn = fminf(fminf(red[0].x, red[1].x), fminf(red[2].x, red[3].x));
+    mx = fmaxf(fmaxf(red[0].y, red[1].y), fmaxf(red[2].y, red[3].y));
+    float fscale, fshift;
+    minmax_to_scale_shift(mn, mx, fscale, fshift);
+    for (int r = 0; r < R; ++r)
+        for (int g = 0; g < G; ++g) {
+            const int r0 = ((r * nwg + w) * G + g) * 4;
+            for (int b = 0; b < 4; ++b) {
+                const int row = r0 + b;
+                if (row >= a.M || row >= na.rows) continue;
+                for (int n = threadIdx.x; n < na.cols; n += 256) {
+                    const float p = a.dst_real[(size_t)row * L + n] * fscale;
+                    na.out[(size_t)row * na.out_stride + n] = p + fshift;
+                }
+            }
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) na.fallback[w] = 0u;
 }
 
 template <int LOGL>
@@ -374,6 +699,62 @@ hipError_t launch_rows4(int logl, RowIn in, RowOut out, const RowArgs& a, const 
 int rows4_minmax_partials(int logl, int M) {
     FDR_DISPATCH_LOG(logl, rows4_partials_t<LG>(M));
     return 0;
+}
+
+template <int LOGL>
+static int rows4_fused_geometry_t(int M, int num_cu, int* R, int* nwg) {
+    if constexpr (LOGL < 5 || LOGL > 12) {
+        return 0;  // half spectrum needs N >= 32; 8192-point rows leave no registers to keep results in
+    } else {
+        constexpr int G = Rows4PackGeom<LOGL>::G;
+        const int groups = (M + 3) / 4;
+        const int wg1 = (groups + G - 1) / G;           // workgroups at one row group per thread group
+        int r = (wg1 + num_cu - 1) / num_cu;
+        if (r == 3) r = 4;
+        if (r < 1 || r > 4 || num_cu <= 0) return 0;
+        *R = r;
+        *nwg = (groups + G * r - 1) / (G * r);           // <= num_cu: one workgroup per CU is always resident
+        return 1;
+    }
+}
+int rows4_fused_geometry(int logl, int M, int num_cu, int* R, int* nwg) {
+    FDR_DISPATCH_LOG(logl, rows4_fused_geometry_t<LG>(M, num_cu, R, nwg));
+    return 0;
+}
+
+template <int LOGL>
+static hipError_t launch_rows4_inv_norm_t(int R, int nwg, const RowArgs& a, const NormArgs& na, const float2* tw, hipStream_t s) {
+    if constexpr (LOGL < 5 || LOGL > 12) {
+        return hipErrorInvalidValue;
+    } else {
+        const dim3 grid(nwg), block(Rows4PackGeom<LOGL>::THREADS);
+        if (R == 1) hipLaunchKernelGGL((fft_rows4_inv_norm_kernel<LOGL, 1>), grid, block, 0, s, a, na, tw);
+        else if (R == 2) hipLaunchKernelGGL((fft_rows4_inv_norm_kernel<LOGL, 2>), grid, block, 0, s, a, na, tw);
+        else if (R == 4) hipLaunchKernelGGL((fft_rows4_inv_norm_kernel<LOGL, 4>), grid, block, 0, s, a, na, tw);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
+}
+hipError_t launch_rows4_inv_norm(int logl, int R, int nwg, const RowArgs& a, const NormArgs& na, const float2* tw_fwd, hipStream_t s) {
+    FDR_DISPATCH_LOG(logl, launch_rows4_inv_norm_t<LG>(R, nwg, a, na, tw_fwd, s));
+    return hipErrorInvalidValue;
+}
+
+template <int LOGL>
+static hipError_t launch_normalize_fixup_t(int R, int nwg, const RowArgs& a, const NormArgs& na, hipStream_t s) {
+    if constexpr (LOGL < 5 || LOGL > 12) {
+        return hipErrorInvalidValue;
+    } else {
+        if (R == 1) hipLaunchKernelGGL((normalize_fixup_kernel<LOGL, 1>), dim3(nwg), dim3(256), 0, s, a, na);
+        else if (R == 2) hipLaunchKernelGGL((normalize_fixup_kernel<LOGL, 2>), dim3(nwg), dim3(256), 0, s, a, na);
+        else if (R == 4) hipLaunchKernelGGL((normalize_fixup_kernel<LOGL, 4>), dim3(nwg), dim3(256), 0, s, a, na);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
+}
+hipError_t launch_normalize_fixup(int logl, int R, int nwg, const RowArgs& a, const NormArgs& na, hipStream_t s) {
+    FDR_DISPATCH_LOG(logl, launch_normalize_fixup_t<LG>(R, nwg, a, na, s));
+    return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -675,78 +1056,115 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::PIPE_WAV
 // ---------------------------------------------------------------------------------------------
 template <int LOGM>
 __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PER_SIMD) void fft_cols_panel_fused_lean_kernel(
-    const PanelBatch pb, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const size_t pstride,
+    const PanelBatch pb, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const unsigned pstride,
     const int npanels, const int ntiles, const int packed0) {
     using St = Steps<LOGM>;
     using Geo = PanelGeom<LOGM>;
     constexpr int G = Geo::G, T = St::T, M = St::L;
     using Core = FftCore<LOGM, 4, 2, PolicyFast>;
     __shared__ float2 lds[G * 2 * St::BUF];
-    const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
+    const int g = G == 1 ? 0 : (int)(threadIdx.x >> St::LOGT);
+    const int tid = threadIdx.x & (T - 1);
     float2* grp_lds = lds + g * 2 * St::BUF;
     const int img = blockIdx.x / ntiles, tl = blockIdx.x - img * ntiles;
-    float2* __restrict__ data = img == 0 ? pb.data[0] : img == 1 ? pb.data[1] : img == 2 ? pb.data[2] : pb.data[3];
-    const int p = tl * G + g;
-    const bool active = p < npanels;
-    const size_t poff = (size_t)(active ? p : 0) * pstride;
+    const bool active = tl * G + g < npanels;
+    // uniform tile bases + one 32-bit per-lane element offset (see tile_load)
+    const size_t tbase = (size_t)(tl * G) * pstride;
+    float2* __restrict__ data = (img == 0 ? pb.data[0] : img == 1 ? pb.data[1] : img == 2 ? pb.data[2] : pb.data[3]) + tbase;
+    const float2* __restrict__ tfilt = filt + tbase;
+    const unsigned loff = (active ? (unsigned)g : 0u) * pstride + (unsigned)tid * 4u;
 
     typename Core::Bases bases;
     Core::init_bases(bases, tw_fwd, tid);
 
     float2 v[4][8];
-    panel_load_in<Core>(data + poff, tid, v);
+    tile_load<Core, false>(data, loff, 1u, v);
     Core::template run<0, false>(v, grp_lds, tw_fwd, bases, tid);
 
     const bool packed_tile = packed0 && tl == 0;  // uniform per workgroup
     constexpr int SEQ = Core::SLOTS;
-    float2* bufc = grp_lds + (SEQ & 1) * St::BUF;
-    float2* bufs = grp_lds + ((SEQ + 1) & 1) * St::BUF;
-    if (packed_tile) {  // mirror exchange of the packed column and of its filter slot column (see packed_column_filter)
+    if (packed_tile) {
+        // Column 0 of panel 0 (packed DC + i Nyquist, see packed_column_filter) is finished here on its own -- mirror
+        // exchange through LDS, two filters, re-pack -- and then rides through the common multiply below with W = 1.
+        // Only v[0][*] changes, so this once-per-image path adds little to the register pressure of the common one.
+        float2* bufc = grp_lds + (SEQ & 1) * St::BUF;
+        float2* bufs = grp_lds + ((SEQ + 1) & 1) * St::BUF;
+        float2 sl[8];
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < Core::NUL; ++u)
 #pragma unroll
             for (int q = 0; q < Core::RHOL; ++q) {
+                const int s = u * Core::RHOL + q;
                 const int k = Core::out_index(tid, u, q);
-                bufc[k] = v[0][u * Core::RHOL + q];
-                bufs[k] = filt[poff + (size_t)k * 4];
+                sl[s] = tfilt[loff - (unsigned)tid * 4u + (unsigned)k * 4u];
+                bufc[k] = v[0][s];
+                bufs[k] = sl[s];
             }
         __syncthreads();
-    }
+        if (g == 0) {
 #pragma unroll
-    for (int u = 0; u < Core::NUL; ++u)
+            for (int u = 0; u < Core::NUL; ++u)
 #pragma unroll
-        for (int q = 0; q < Core::RHOL; ++q) {
-            const int s = u * Core::RHOL + q;
-            const int k = Core::out_index(tid, u, q);
-            float2 w0, w1, w2, w3;
-            load4(filt + poff + (size_t)k * 4, w0, w1, w2, w3);
-            if (packed_tile && g == 0) {
-                const int km = (M - k) & (M - 1);
-                const float2 c = v[0][s], cm = bufc[km], sl = w0, sm = bufs[km];
-                const float2 f0 = make_float2(0.5f * (c.x + cm.x), 0.5f * (c.y - cm.y));
-                const float2 fn = make_float2(0.5f * (c.y + cm.y), 0.5f * (cm.x - c.x));
-                float2 a0, an;
-                if (k == 0 || k == M / 2) { a0 = make_float2(sl.x, 0.f); an = make_float2(sl.y, 0.f); }
-                else if (k < M / 2) { a0 = sl; an = sm; }
-                else { a0 = make_float2(sm.x, -sm.y); an = make_float2(sl.x, -sl.y); }
-                const float2 z0 = cmul_fma(f0, a0), zn = cmul_fma(fn, an);
-                v[0][s] = make_float2(z0.x - zn.y, z0.y + zn.x);
-            } else {
-                v[0][s] = cmul_fma(v[0][s], w0);
-            }
-            v[1][s] = cmul_fma(v[1][s], w1);
-            v[2][s] = cmul_fma(v[2][s], w2);
-            v[3][s] = cmul_fma(v[3][s], w3);
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int s = u * Core::RHOL + q;
+                    const int k = Core::out_index(tid, u, q);
+                    const int km = (M - k) & (M - 1);
+                    const float2 c = v[0][s], cm = bufc[km], sm = bufs[km];
+                    const float2 f0 = make_float2(0.5f * (c.x + cm.x), 0.5f * (c.y - cm.y));
+                    const float2 fn = make_float2(0.5f * (c.y + cm.y), 0.5f * (cm.x - c.x));
+                    float2 a0, an;
+                    if (k == 0 || k == M / 2) { a0 = make_float2(sl[s].x, 0.f); an = make_float2(sl[s].y, 0.f); }
+                    else if (k < M / 2) { a0 = sl[s]; an = sm; }
+                    else { a0 = make_float2(sm.x, -sm.y); an = make_float2(sl[s].x, -sl[s].y); }
+                    const float2 z0 = cmul_fma(f0, a0), zn = cmul_fma(fn, an);
+                    v[0][s] = make_float2(z0.x - zn.y, z0.y + zn.x);
+                }
         }
-    if (packed_tile) __syncthreads();  // both buffers were read above
+        __syncthreads();  // both buffers were read above
+    }
+    {
+        const bool col0_done = packed_tile && g == 0;
+        // W in four pieces of two slots (16 VGPRs each), the next piece requested before the current one is used; the
+        // compiler barriers keep it from hoisting all 16 loads to the top (64 more live registers = spills at 128)
+        auto wload = [&](int h, float2 (&w)[2][4]) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int s = 2 * h + i, u = s / Core::RHOL, q = s % Core::RHOL;
+                const unsigned uoff = (unsigned)(((q << Core::LOGOUT) + u * Core::T) * 4);
+                load4(tfilt + uoff + loff, w[i][0], w[i][1], w[i][2], w[i][3]);
+            }
+        };
+        auto wmul = [&](int h, const float2 (&w)[2][4]) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int s = 2 * h + i;
+                v[0][s] = cmul_fma(v[0][s], col0_done ? make_float2(1.f, 0.f) : w[i][0]);
+                v[1][s] = cmul_fma(v[1][s], w[i][1]);
+                v[2][s] = cmul_fma(v[2][s], w[i][2]);
+                v[3][s] = cmul_fma(v[3][s], w[i][3]);
+            }
+        };
+        float2 wa[2][4], wb[2][4];
+        wload(0, wa);
+        asm volatile("" ::: "memory");
+        wload(1, wb);
+        wmul(0, wa);
+        asm volatile("" ::: "memory");
+        wload(2, wa);
+        wmul(1, wb);
+        asm volatile("" ::: "memory");
+        wload(3, wb);
+        wmul(2, wa);
+        wmul(3, wb);
+    }
     if constexpr (Core::RHOL != Core::RHO0) {
         redistribute<LOGM, Core, SEQ>(v, grp_lds, tid);
         Core::template run<SEQ + 4, true>(v, grp_lds, tw_fwd, bases, tid);
     } else {
         Core::template run<SEQ, true>(v, grp_lds, tw_fwd, bases, tid);
     }
-    if (active) panel_store_out<Core>(data + poff, tid, v);
+    if (active) tile_store<Core>(data, loff, v);
 }
 
 template <int LOGM>
@@ -766,7 +1184,7 @@ static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const floa
         // threads per transform leave no room for a second set), on request (FDR_FLAG_LEAN_COLS) otherwise
         if (Geo::THREADS >= 1024 || a.lean) {
             hipLaunchKernelGGL((fft_cols_panel_fused_lean_kernel<LOGM>), dim3(total), dim3(Geo::THREADS), 0, s, pb, a.filt, tw,
-                               ps, npanels, ntiles, a.packed0);
+                               (unsigned)ps, npanels, ntiles, a.packed0);
             return hipGetLastError();
         }
         int grid = (a.num_cu > 0 ? a.num_cu : 256) * Geo::PIPE_WG_PER_CU;

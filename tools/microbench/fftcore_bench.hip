@@ -16,13 +16,15 @@ __global__ __launch_bounds__(Steps<LOGL>::T, MINW) void core_loop(float2* data, 
     __shared__ float2 lds[NBUF * St::BUF];
     const int tid = threadIdx.x;
     float2 v[B][8];
+    typename Core::Bases bases;
+    Core::init_bases(bases, tw, tid);
     float2* base = data + (size_t)blockIdx.x * B * St::L;
 #pragma unroll
     for (int b = 0; b < B; ++b)
 #pragma unroll
         for (int s = 0; s < 8; ++s) v[b][s] = base[b * St::L + tid + s * St::T];
     for (int r = 0; r < reps; ++r) {
-        Core::template run<0>(v, lds, tw, tid);
+        Core::template run<0, true>(v, lds, tw, bases, tid);
         if (NBUF == 2 && (Core::SLOTS & 1)) __syncthreads();  // keep buffer parity hazard-free across reps
         if (NBUF == 2) __syncthreads();
     }
@@ -63,6 +65,8 @@ int main() {
     std::vector<float2> h(8192);
     for (int i = 0; i < 8192; ++i) h[i] = make_float2(1.f, 0.f);
     CK(hipMalloc(&tw, 8192 * 8)); CK(hipMemcpy(tw, h.data(), 8192 * 8, hipMemcpyHostToDevice));
+    run<12, 2, 2, PolicyFast, 1>("B=2 NBUF=2, ONE workgroup per CU", data, tw, 1);
+    run<12, 4, 2, PolicyFast, 1>("B=4 NBUF=2, ONE workgroup per CU", data, tw, 1);
     run<12, 1, 1, PolicyFast, 1>("row-like B=1 NBUF=1", data, tw, 4);
     run<12, 1, 1, PolicyParity, 1>("row-like B=1 NBUF=1 parity", data, tw, 4);
     run<12, 1, 2, PolicyFast, 1>("row-like B=1 NBUF=2", data, tw, 2);
