@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--mode", choices=["fast", "parity"], default="fast")
     ap.add_argument("--streams", type=int, default=2, help="internal streams / workspaces the batch alternates over")
-    ap.add_argument("--group", type=int, default=2, help="images per pass-B' launch (fast mode; 1..4, streams*group <= 8)")
+    ap.add_argument("--group", type=int, default=0, help="images per pass-B' launch (fast mode; 1..4, streams*group <= 8; 0 = 4 up to 2048^2, else 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=0, help="edge of the CPU-baseline sample (default: --size, capped at 4096)")
     return ap.parse_args()
@@ -120,11 +120,15 @@ def main():
         flags |= fdr.FLAG_FULL_SPECTRUM
     if os.environ.get("FDR_LEAN_COLS") == "1":
         flags |= fdr.FLAG_LEAN_COLS
+    if os.environ.get("FDR_COLS8") == "1":
+        flags |= fdr.FLAG_COLS8
     if os.environ.get("FDR_FUSED_NORM") == "1":
         flags |= fdr.FLAG_FUSED_NORM
     spectrum = "half" if (args.mode == "fast" and not (flags & fdr.FLAG_FULL_SPECTRUM) and S >= 32) else "full"
     plan = fdr.Plan(S, S, mode, device=local_rank, flags=flags)
     stream = torch.cuda.current_stream().cuda_stream
+    if args.group <= 0:
+        args.group = 4 if S <= 2048 else 1  # small images: several per column launch fill the chip (measured)
     plan.set_batching(args.streams, args.group if args.mode == "fast" else 1)
     plan.set_psf_motion(50, 30.0, 0.01, stream=stream)  # PSF generated, padded and transformed on the device
     imgs = torch.empty((B, S, S), dtype=torch.float32, device=dev)

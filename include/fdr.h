@@ -69,6 +69,11 @@ extern "C" {
                                     other images' passes in the batched multi-stream mode, where the two-launch form is
                                     faster (measured: DESIGN.md section 5).                                           */
 
+#define FDR_FLAG_COLS8 256u /* fast mode, columns of 1024 points and more: the radix-8 persistent kernel (8 values per
+                               thread, one 512-thread workgroup per CU, software-pipelined) instead of the default
+                               pass B' with 16 values per thread (radix-16 steps: a 4-column tile is one 256-thread
+                               workgroup, two of which share a CU).  A/B measurements.                            */
+
 /* normalisation area selector for fdr_wiener_* */
 #define FDR_NORM_PADDED 1  /* serial semantics: min/max over the padded M x N area, then crop
                               (serial.cpp:36-38 + fft/fft_serial.cpp:243-246)                 */

@@ -28,6 +28,7 @@ FLAG_POW2_PANELS = 16
 FLAG_FULL_SPECTRUM = 32
 FLAG_LEAN_COLS = 64
 FLAG_FUSED_NORM = 128
+FLAG_COLS8 = 256
 NORM_PADDED = 1
 NORM_CROPPED = 0
 MAX_PASSES = 8

@@ -243,6 +243,13 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
 
 #ifdef FDR_DEBUG_STAMPS
 unsigned long long* g_debug_stamps = nullptr;
+unsigned long long* debug_stamps() {  // timing-only builds: one pinned buffer per process, dumped by fdr_debug_dump_stamps
+    if (!g_debug_stamps) {
+        (void)hipHostMalloc((void**)&g_debug_stamps, 2048 * 32 * sizeof(unsigned long long));
+        memset(g_debug_stamps, 0, 2048 * 32 * 8);
+    }
+    return g_debug_stamps;
+}
 #endif
 
 int ensure_fused_sync(fdr_plan* p, fdr_plan::Slot& w) {
@@ -270,8 +277,12 @@ int panel_stage_B(fdr_plan* p, fdr_plan::Slot* const* ws, int n, hipStream_t s) 
     ColArgs c{};
     c.data = ws[0]->work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu; c.no_pipeline = p->no_pipeline;
     c.lean = (p->flags & FDR_FLAG_LEAN_COLS) != 0;
+    c.v16 = (p->flags & (FDR_FLAG_COLS8 | FDR_FLAG_LEAN_COLS | FDR_FLAG_NO_PIPELINE)) == 0;  // default from 1024-point columns up
     c.pstride = p->pstride; c.npanels = p->npanels; c.packed0 = p->half ? 1 : 0;
     c.batch.nimg = n;
+#ifdef FDR_DEBUG_STAMPS
+    if (getenv("FDR_STAMP_COLS")) c.batch.stamps = debug_stamps();
+#endif
     for (int k = 0; k < n; ++k) c.batch.data[k] = ws[k]->work;
     FDR_HIP(launch_cols_panel(p->logM, COL_FUSED, c, p->tw_col_f, s));
     return FDR_OK;
@@ -289,11 +300,7 @@ int panel_stage_CE(fdr_plan* p, fdr_plan::Slot& w, int rows, int cols, float* d_
         na.gran = w.gran; na.fallback = w.fallback; na.epoch = w.epoch; na.spin_limit = p->spin_limit;
         na.out = d_out; na.rows = rows; na.cols = cols; na.out_stride = out_stride;
 #ifdef FDR_DEBUG_STAMPS
-        {   // timing-only builds: one pinned buffer per process, dumped by fdr_debug_dump_stamps
-            static unsigned long long* g_stamps = nullptr;
-            if (!g_stamps) { (void)hipHostMalloc((void**)&g_stamps, 1024 * 32 * sizeof(unsigned long long)); memset(g_stamps, 0, 1024 * 32 * 8); g_debug_stamps = g_stamps; }
-            na.stamps = g_stamps;
-        }
+        na.stamps = debug_stamps();
 #endif
         {
             ScopedPass t(p, s, kPassRowsInvNorm);

@@ -25,15 +25,20 @@ namespace fdr {
 // compile-time step plan for L = 2^LOGL: small radix first (so only radix-8 steps ever read a
 // padded layout), T = L/8 threads per transform.
 // ---------------------------------------------------------------------------------------------
-template <int LOGL>
+// LOGV = log2 of the values a thread holds per transform: 3 (8 values, radix-8 steps; every kernel but one) or 4
+// (16 values, radix-16 steps: half the threads and two LDS exchanges instead of three for 4096 points -- the
+// column pass, where 4 columns x 16 values = 128 registers per lane buy two 256-thread workgroups per CU).
+template <int LOGL, int LOGV = 3>
 struct Steps {
     static_assert(LOGL >= 1 && LOGL <= 13, "transform length 2..8192");
+    static_assert(LOGV == 3 || LOGV == 4, "8 or 16 values per thread");
     static constexpr int L = 1 << LOGL;
-    static constexpr int REM = LOGL % 3;
-    static constexpr int S = LOGL / 3 + (REM ? 1 : 0);
-    static constexpr int LOGT = LOGL >= 3 ? LOGL - 3 : 0;
+    static constexpr int V = 1 << LOGV;
+    static constexpr int REM = LOGL % LOGV;
+    static constexpr int S = LOGL / LOGV + (REM ? 1 : 0);
+    static constexpr int LOGT = LOGL >= LOGV ? LOGL - LOGV : 0;
     static constexpr int T = 1 << LOGT;  // threads per transform
-    __host__ __device__ static constexpr int lr(int j) { return (REM != 0 && j == 0) ? REM : 3; }
+    __host__ __device__ static constexpr int lr(int j) { return (REM != 0 && j == 0) ? REM : LOGV; }
     __host__ __device__ static constexpr int lprev(int j) {
         int s = 0;
         for (int i = 0; i < j; ++i) s += lr(i);
@@ -41,9 +46,9 @@ struct Steps {
     }
     __host__ __device__ static constexpr int logR(int j) { return LOGL - lprev(j) - lr(j); }
     // butterflies per thread at step j (L < 8: a single partial butterfly on one thread)
-    __host__ __device__ static constexpr int nu(int j) { return LOGL >= 3 ? (8 >> lr(j)) : 1; }
+    __host__ __device__ static constexpr int nu(int j) { return LOGL >= LOGV ? (V >> lr(j)) : 1; }
     // LDS elements (float2) of one exchange buffer, including read-side padding
-    static constexpr int BUF = L + (L >> 3) + 8;
+    static constexpr int BUF = L + (L >> 3) + 8;  // (LOGV = 4 pads by at most L/16)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -182,6 +187,71 @@ __device__ __forceinline__ void radix_step(float2* x, const TwSet& t) {
     }
 }
 
+// Radix-16 step of the fast policy on B transforms at once, STAGE-major (stage t of all B transforms before stage
+// t+1), so that only one stage's twiddles are live: 1, 2, 4, then 8 complex values, all derived from the ONE hoisted
+// table value w = exp(-+2 pi i k / (16 LP)):  stage 1: w^8;  stage 2: w^4 {1, -+i};  stage 3: w^2 {1, e^(-+i pi/4)} x
+// {1, -+i};  stage 4: w {1, e^(-+i pi/8), e^(-+i pi/4), e^(-+3i pi/8)} x {1, -+i}.  Pair (i, i + 16/2^t) of block j
+// uses T_{2^t LP}[k + LP bitrev(j)], exactly the radix-8 scheme one level deeper; outputs leave in bit-reversed
+// order and are put back by six swaps.
+template <int B, int V, bool INV>
+__device__ __forceinline__ void radix16_fast(float2 (&v)[B][V], float2 base) {
+    static_assert(V == 16, "16 values per thread");
+    using P = PolicyFast;
+    asm volatile("" : "+v"(base.x), "+v"(base.y));  // as in PolicyFast::twiddles: keep the derived set out of LICM's reach
+    const float2 w = INV ? make_float2(base.x, -base.y) : base;
+    auto rot = [](float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); };  // times -+i
+    const float2 w2 = P::csq(w), w4 = P::csq(w2);
+    {   // stage 1
+        const float2 w8 = P::csq(w4);
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) P::bfly(v[b][i], v[b][i + 8], w8);
+    }
+    {   // stage 2
+        const float2 t0 = w4, t1 = rot(w4);
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                P::bfly(v[b][i], v[b][i + 4], t0);
+                P::bfly(v[b][8 + i], v[b][12 + i], t1);
+            }
+    }
+    const float c4 = 0.70710678118654752440f;
+    {   // stage 3: blocks j = 0..3 -> w2 * omega_8^bitrev2(j) = {0, 2, 1, 3}
+        const float2 d = INV ? make_float2(c4 * (w2.x - w2.y), c4 * (w2.x + w2.y)) : make_float2(c4 * (w2.x + w2.y), c4 * (w2.y - w2.x));
+        const float2 t[4] = {w2, rot(w2), d, rot(d)};
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                P::bfly(v[b][4 * j], v[b][4 * j + 2], t[j]);
+                P::bfly(v[b][4 * j + 1], v[b][4 * j + 3], t[j]);
+            }
+    }
+    {   // stage 4: blocks j = 0..7 -> w * omega_16^bitrev3(j) = {0, 4, 2, 6, 1, 5, 3, 7}
+        const float c8 = 0.92387953251128675613f, s8 = 0.38268343236508977173f;  // cos, sin of pi/8
+        auto mulc = [](float2 a, float cr, float ci) {  // a * (cr + i ci)
+            return make_float2(__builtin_fmaf(a.x, cr, -(a.y * ci)), __builtin_fmaf(a.x, ci, a.y * cr));
+        };
+        const float sg = INV ? 1.0f : -1.0f;                      // omega_16 = exp(-+i pi/8)
+        const float2 e1 = mulc(w, c8, sg * s8);                   // w omega^1
+        const float2 e2 = mulc(w, c4, sg * c4);                   // w omega^2
+        const float2 e3 = mulc(w, s8, sg * c8);                   // w omega^3
+        const float2 t[8] = {w, rot(w), e2, rot(e2), e1, rot(e1), e3, rot(e3)};
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) P::bfly(v[b][2 * j], v[b][2 * j + 1], t[j]);
+    }
+#pragma unroll
+    for (int b = 0; b < B; ++b) {  // 4-bit reversal
+        swap2(v[b][1], v[b][8]); swap2(v[b][2], v[b][4]); swap2(v[b][3], v[b][12]);
+        swap2(v[b][5], v[b][10]); swap2(v[b][7], v[b][14]); swap2(v[b][11], v[b][13]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // FftCore<LOGL, B, NBUF, Pol>: B independent transforms per thread group of T threads.
 //   v[b][u*RHO + q]  on entry : x_b[(tid + T u) + R_0 q]          (first-step operand order)
@@ -189,9 +259,10 @@ __device__ __forceinline__ void radix_step(float2* x, const TwSet& t) {
 // lds: this group's NBUF * Steps::BUF float2 region.  SEQ0: how many exchange slots were already
 // consumed on this region (keeps the double-buffer parity hazard-free across chained calls).
 // ---------------------------------------------------------------------------------------------
-template <int LOGL, int B, int NBUF, class Pol>
+template <int LOGL, int B, int NBUF, class Pol, int LOGV = 3>
 struct FftCore {
-    using St = Steps<LOGL>;
+    using St = Steps<LOGL, LOGV>;
+    static constexpr int V = St::V;
     static constexpr int S = St::S;
     static constexpr int T = St::T;
     static constexpr int SLOTS = (S - 1) * B;  // exchange slots one run() consumes
@@ -204,7 +275,7 @@ struct FftCore {
     static __device__ __forceinline__ int out_index(int tid, int u, int q) { return (tid + u * T) + (q << LOGOUT); }
 
     // per-thread hoisted twiddle bases (fast policy): one value per step and butterfly slot
-    struct Bases { float2 b[S][4]; };
+    struct Bases { float2 b[S][V / 2]; };
 
     template <int J>
     static __device__ __forceinline__ void init_bases_from(Bases& bs, const float2* __restrict__ tw, int tid) {
@@ -226,19 +297,24 @@ struct FftCore {
     }
 
     template <int J, bool INV>
-    static __device__ __forceinline__ void butterflies(float2 (&v)[B][8], const float2* __restrict__ tw, const Bases& bs, int tid) {
+    static __device__ __forceinline__ void butterflies(float2 (&v)[B][V], const float2* __restrict__ tw, const Bases& bs, int tid) {
         constexpr int LR = St::lr(J), NU = St::nu(J), RHO = 1 << LR, LOGR = St::logR(J), LP = 1 << St::lprev(J);
+        if constexpr (LR == 4) {
+            static_assert(Pol::kHoist, "radix-16 steps exist for the fast policy only");
+            radix16_fast<B, V, INV>(v, bs.b[J][0]);  // NU == 1: the 16 values of a thread are one butterfly
+        } else {
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int k = (tid + u * T) >> LOGR;
-            const TwSet t = Pol::template twiddles<LR, LP, INV>(tw, k, bs.b[J][u]);
+            for (int u = 0; u < NU; ++u) {
+                const int k = (tid + u * T) >> LOGR;
+                const TwSet t = Pol::template twiddles<LR, LP, INV>(tw, k, bs.b[J][u]);
 #pragma unroll
-            for (int b = 0; b < B; ++b) radix_step<LR, Pol>(&v[b][u * RHO], t);
+                for (int b = 0; b < B; ++b) radix_step<LR, Pol>(&v[b][u * RHO], t);
+            }
         }
     }
 
     template <int J, int SEQ0>
-    static __device__ __forceinline__ void exchange(float2 (&v)[B][8], float2* lds, int tid) {
+    static __device__ __forceinline__ void exchange(float2 (&v)[B][V], float2* lds, int tid) {
         constexpr int LR = St::lr(J), NU = St::nu(J), RHO = 1 << LR;
         constexpr int LRn = St::lr(J + 1), NUn = St::nu(J + 1), RHOn = 1 << LRn, LOGRn = St::logR(J + 1);
 #pragma unroll
@@ -262,7 +338,7 @@ struct FftCore {
     }
 
     template <int J, int SEQ0, bool INV>
-    static __device__ __forceinline__ void steps_from(float2 (&v)[B][8], float2* lds, const float2* __restrict__ tw,
+    static __device__ __forceinline__ void steps_from(float2 (&v)[B][V], float2* lds, const float2* __restrict__ tw,
                                                       const Bases& bs, int tid) {
         butterflies<J, INV>(v, tw, bs, tid);
         if constexpr (J + 1 < S) {
@@ -273,7 +349,7 @@ struct FftCore {
 
     // tw: parity -> the direction-specific recurrence table; fast -> unused once bases are hoisted
     template <int SEQ0, bool INV>
-    static __device__ __forceinline__ void run(float2 (&v)[B][8], float2* lds, const float2* __restrict__ tw, const Bases& bs,
+    static __device__ __forceinline__ void run(float2 (&v)[B][V], float2* lds, const float2* __restrict__ tw, const Bases& bs,
                                                int tid) {
 #ifdef FDR_DEBUG_SKIP_FFT  // timing-only builds (tools/microbench): memory phases without the transform
         (void)lds; (void)tw; (void)bs; (void)tid; (void)v;

@@ -53,6 +53,7 @@ struct NormArgs {
 struct PanelBatch {
     float2* data[4];
     int nimg;  // 0 or 1: use ColArgs::data only
+    unsigned long long* stamps;  // timing-only builds (FDR_DEBUG_STAMPS), else unused
 };
 
 struct ColArgs {
@@ -65,6 +66,7 @@ struct ColArgs {
     int N;  // row length (number of columns)
     int npanels;      // panel kernels: number of panels (0 = N/4)
     PanelBatch batch; // panel kernels, COL_FUSED: several images per launch
+    int v16;          // panel kernels, COL_FUSED: 16-values-per-thread kernel (columns of >= 1024 points)
     int lean;         // panel kernels, COL_FUSED: single-register-set kernel, one workgroup per tile
     int packed0;      // panel kernels: column 0 of panel 0 is the packed DC + i Nyquist column (half spectrum)
     size_t pstride;   // panel kernels: panel stride in float2 elements

@@ -811,8 +811,8 @@ __device__ __forceinline__ void panel_store_out(float2* __restrict__ pbase, int 
 
 // last-step result order -> first-step operand order through LDS when the two radices differ
 template <int LOGM, class Core, int SEQ>
-__device__ __forceinline__ void redistribute(float2 (&cur)[4][8], float2* grp_lds, int tid) {
-    using St = Steps<LOGM>;
+__device__ __forceinline__ void redistribute(float2 (&cur)[4][Core::V], float2* grp_lds, int tid) {
+    using St = typename Core::St;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         float2* buf = grp_lds + ((SEQ + b) & 1) * St::BUF;
@@ -903,27 +903,60 @@ __device__ __forceinline__ void packed_column_filter(float2 (&cur)[4][8], const 
 // -- a conditional prefetch makes PHIs of (loaded, old) values whose copies hipcc places right behind the loads,
 // i.e. it waits for the prefetch before the transform it was meant to hide behind (seen in the ISA as
 // `vmcnt(11) .. vmcnt(1)` directly after the 16 loads).
+// Pins a wave-uniform GLOBAL address in an SGPR pair.  Without it hipcc re-associates (uniform base + constant) +
+// lane offset into (base + lane offset) + constant: one 64-bit VGPR address per load, kept alive for the stores of the
+// same tile -- 30+ registers that end up spilled in the 128-data-register kernels.  The pointer keeps its address
+// space through the asm (a generic pointer would turn every access into a flat_load).
+typedef float nfloat4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) char gchar;
+typedef __attribute__((address_space(1))) nfloat4 g_nfloat4;
+__device__ __forceinline__ gchar* uniform_gptr(const void* p) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (gchar*)(((unsigned long long)hi << 32) | lo);
+}
+// 32 bytes at (uniform base) + (32-bit lane byte offset): global_load_dwordx4 v, v_off, s[base:base+1] {offset:16}.
+// (HIP's float4, field by field: with native vector types the two halves reach the register arrays as <2 x float>
+// stores, which SROA does not promote -- the arrays then live in scratch memory.)
+#define FDR_GLOAD32(ub, lane_bytes, a, b, c, d)                                                       \
+    do {                                                                                              \
+        const float4* p_ = reinterpret_cast<const float4*>((const char*)(ub) + (lane_bytes));         \
+        const float4 x0_ = p_[0], x1_ = p_[1];                                                        \
+        a = make_float2(x0_.x, x0_.y); b = make_float2(x0_.z, x0_.w);                                 \
+        c = make_float2(x1_.x, x1_.y); d = make_float2(x1_.z, x1_.w);                                 \
+    } while (0)
+__device__ __forceinline__ void gstore32(gchar* ub, unsigned lane_bytes, float2 a, float2 b, float2 c, float2 d) {
+    float4* p = reinterpret_cast<float4*>((char*)ub + lane_bytes);
+    p[0] = make_float4(a.x, a.y, b.x, b.y);
+    p[1] = make_float4(c.x, c.y, d.x, d.y);
+}
+
 template <class Core, bool OUT_ORDER>
-__device__ __forceinline__ void tile_load(const float2* __restrict__ ubase, unsigned loff, unsigned scale, float2 (&d)[4][8]) {
+__device__ __forceinline__ void tile_load(const float2* __restrict__ ubase, unsigned loff, unsigned scale, float2 (&d)[4][Core::V]) {
     constexpr int NU = OUT_ORDER ? Core::NUL : Core::NU0, RHO = OUT_ORDER ? Core::RHOL : Core::RHO0;
     constexpr int LOGQ = OUT_ORDER ? Core::LOGOUT : Core::LOGR0;
-    const unsigned lo = loff * scale;
+    // byte offsets in 32 bits: (uniform 64-bit base) + zext(32-bit lane offset) is the form hipcc turns into
+    // `global_load_dwordx4 v, v_off, s[base:base+1]`, i.e. ONE address VGPR for the whole tile
+    const unsigned lo = loff * scale * 8u;
 #pragma unroll
     for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int q = 0; q < RHO; ++q) {
             const int s = u * RHO + q;
-            const unsigned uoff = (unsigned)(((q << LOGQ) + u * Core::T) * 4) * scale;  // uniform
+            const unsigned uoff = (unsigned)(((q << LOGQ) + u * Core::T) * 4) * scale;  // uniform, elements
 #ifdef FDR_DEBUG_SKIP_MEM  // timing-only builds: pass B' without its HBM traffic
             (void)ubase; (void)uoff;
             d[0][s] = d[1][s] = d[2][s] = d[3][s] = make_float2(__uint_as_float(lo), 1.0f);
 #else
-            load4(ubase + uoff + lo, d[0][s], d[1][s], d[2][s], d[3][s]);
+            const gchar* ub = uniform_gptr(ubase + uoff);
+            FDR_GLOAD32(ub, lo, d[0][s], d[1][s], d[2][s], d[3][s]);
 #endif
         }
 }
 template <class Core>
-__device__ __forceinline__ void tile_store(float2* __restrict__ ubase, unsigned loff, const float2 (&d)[4][8]) {
+__device__ __forceinline__ void tile_store(float2* __restrict__ ubase, unsigned loff, const float2 (&d)[4][Core::V]) {
+    const unsigned lo = loff * 8u;
 #pragma unroll
     for (int u = 0; u < Core::NUL; ++u)
 #pragma unroll
@@ -931,10 +964,9 @@ __device__ __forceinline__ void tile_store(float2* __restrict__ ubase, unsigned 
             const int s = u * Core::RHOL + q;
             const unsigned uoff = (unsigned)(((q << Core::LOGOUT) + u * Core::T) * 4);
 #ifdef FDR_DEBUG_SKIP_MEM
-            if (d[0][s].x == 1.2345e-30f) store4(ubase + uoff + loff, d[0][s], d[1][s], d[2][s], d[3][s]);
-#else
-            store4(ubase + uoff + loff, d[0][s], d[1][s], d[2][s], d[3][s]);
+            if (d[0][s].x != 1.2345e-30f) continue;
 #endif
+            gstore32(uniform_gptr(ubase + uoff), lo, d[0][s], d[1][s], d[2][s], d[3][s]);
         }
 }
 
@@ -1014,37 +1046,47 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::PIPE_WAV
     typename Core::Bases bases;
     Core::init_bases(bases, tw_fwd, tid);
 
-    auto tile_of = [&](int gt) {
+    // (image, tile) advance by scalar add / subtract: an integer division per tile would run on the VALU and drag
+    // every tile address into VGPRs
+    auto tile_of = [&](int img, int tl) {
         PanelTile r;
-        const int img = gt / ntiles;
-        r.tl = gt - img * ntiles;
-        r.ok = r.tl * G + g < npanels;
+        r.tl = tl;
+        r.ok = tl * G + g < npanels;
         r.loff = (r.ok ? (unsigned)g : 0u) * pstride + (unsigned)tid * 4u;
-        const size_t tbase = (size_t)(r.tl * G) * pstride;
+        const size_t tbase = (size_t)(tl * G) * pstride;
         r.data = (img == 0 ? pb.data[0] : img == 1 ? pb.data[1] : img == 2 ? pb.data[2] : pb.data[3]) + tbase;
         r.filt = filt + tbase;
         return r;
     };
+    int img = 0, tl = t;
+    while (tl >= ntiles) { tl -= ntiles; ++img; }
+    auto advance = [&](int& im, int& tt) {
+        tt += (int)gridDim.x;
+        while (tt >= ntiles) { tt -= ntiles; ++im; }
+    };
 
     float2 P[4][8], Q[4][8];
-    PanelTile c = tile_of(t);
+    PanelTile c = tile_of(img, tl);
     tile_load<Core, false>(c.data, c.loff, 1u, P);
     tile_load<Core, true>(c.filt, c.loff, 1u, Q);
     while (true) {
         int tn = t + gridDim.x;
         bool more = tn < total;
-        PanelTile n = tile_of(more ? tn : t);
+        int nimg = img, ntl = tl;
+        if (more) advance(nimg, ntl);
+        PanelTile n = tile_of(nimg, ntl);
         if (!more) n.data = const_cast<float2*>(n.filt);  // dummy prefetch source: read-only memory
         panel_tile<LOGM, Core>(P, Q, c, n, more ? 1u : 0u, grp_lds, bases, tw_fwd, tid, packed0 && c.tl == 0, g == 0);
         if (!more) break;
-        t = tn; c = n;
+        t = tn; c = n; img = nimg; tl = ntl;
         tn = t + gridDim.x;
         more = tn < total;
-        n = tile_of(more ? tn : t);
+        if (more) advance(nimg, ntl);
+        n = tile_of(nimg, ntl);
         if (!more) n.data = const_cast<float2*>(n.filt);
         panel_tile<LOGM, Core>(Q, P, c, n, more ? 1u : 0u, grp_lds, bases, tw_fwd, tid, packed0 && c.tl == 0, g == 0);
         if (!more) break;
-        t = tn; c = n;
+        t = tn; c = n; img = nimg; tl = ntl;
     }
 }
 
@@ -1066,7 +1108,8 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PE
     const int g = G == 1 ? 0 : (int)(threadIdx.x >> St::LOGT);
     const int tid = threadIdx.x & (T - 1);
     float2* grp_lds = lds + g * 2 * St::BUF;
-    const int img = blockIdx.x / ntiles, tl = blockIdx.x - img * ntiles;
+    // grid (ntiles, images): an integer division here would run on the VALU and drag every tile address into VGPRs
+    const int img = blockIdx.y, tl = blockIdx.x;
     const bool active = tl * G + g < npanels;
     // uniform tile bases + one 32-bit per-lane element offset (see tile_load)
     const size_t tbase = (size_t)(tl * G) * pstride;
@@ -1089,7 +1132,6 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PE
         // Only v[0][*] changes, so this once-per-image path adds little to the register pressure of the common one.
         float2* bufc = grp_lds + (SEQ & 1) * St::BUF;
         float2* bufs = grp_lds + ((SEQ + 1) & 1) * St::BUF;
-        float2 sl[8];
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < Core::NUL; ++u)
@@ -1097,9 +1139,8 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PE
             for (int q = 0; q < Core::RHOL; ++q) {
                 const int s = u * Core::RHOL + q;
                 const int k = Core::out_index(tid, u, q);
-                sl[s] = tfilt[loff - (unsigned)tid * 4u + (unsigned)k * 4u];
                 bufc[k] = v[0][s];
-                bufs[k] = sl[s];
+                bufs[k] = tfilt[loff - (unsigned)tid * 4u + (unsigned)k * 4u];  // (read back below: no registers held)
             }
         __syncthreads();
         if (g == 0) {
@@ -1110,13 +1151,13 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PE
                     const int s = u * Core::RHOL + q;
                     const int k = Core::out_index(tid, u, q);
                     const int km = (M - k) & (M - 1);
-                    const float2 c = v[0][s], cm = bufc[km], sm = bufs[km];
+                    const float2 c = v[0][s], cm = bufc[km], sm = bufs[km], sl_s = bufs[k];
                     const float2 f0 = make_float2(0.5f * (c.x + cm.x), 0.5f * (c.y - cm.y));
                     const float2 fn = make_float2(0.5f * (c.y + cm.y), 0.5f * (cm.x - c.x));
                     float2 a0, an;
-                    if (k == 0 || k == M / 2) { a0 = make_float2(sl[s].x, 0.f); an = make_float2(sl[s].y, 0.f); }
-                    else if (k < M / 2) { a0 = sl[s]; an = sm; }
-                    else { a0 = make_float2(sm.x, -sm.y); an = make_float2(sl[s].x, -sl[s].y); }
+                    if (k == 0 || k == M / 2) { a0 = make_float2(sl_s.x, 0.f); an = make_float2(sl_s.y, 0.f); }
+                    else if (k < M / 2) { a0 = sl_s; an = sm; }
+                    else { a0 = make_float2(sm.x, -sm.y); an = make_float2(sl_s.x, -sl_s.y); }
                     const float2 z0 = cmul_fma(f0, a0), zn = cmul_fma(fn, an);
                     v[0][s] = make_float2(z0.x - zn.y, z0.y + zn.x);
                 }
@@ -1132,7 +1173,8 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PE
             for (int i = 0; i < 2; ++i) {
                 const int s = 2 * h + i, u = s / Core::RHOL, q = s % Core::RHOL;
                 const unsigned uoff = (unsigned)(((q << Core::LOGOUT) + u * Core::T) * 4);
-                load4(tfilt + uoff + loff, w[i][0], w[i][1], w[i][2], w[i][3]);
+                const gchar* ub = uniform_gptr(tfilt + uoff);
+                FDR_GLOAD32(ub, loff * 8u, w[i][0], w[i][1], w[i][2], w[i][3]);
             }
         };
         auto wmul = [&](int h, const float2 (&w)[2][4]) {
@@ -1167,6 +1209,149 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PE
     if (active) tile_store<Core>(data, loff, v);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pass B' with 16 values per thread (radix-16 steps): a 4096-point column takes 256 threads, so a 4-column tile is
+// ONE 256-thread workgroup holding 128 data registers per lane, and two such workgroups share a CU (2 x 74 KB of LDS,
+// 256 VGPRs each): the hardware overlaps one tile's loads / stores with the other tile's transforms, which the
+// single persistent workgroup of the radix-8 kernel has to arrange by hand (and only half manages: DESIGN.md 5).
+// 8192-point columns: 512 threads, one workgroup per CU, no spills (the radix-8 kernel needs 1024 threads at 128
+// VGPRs there).  One tile per workgroup; the tile sequence runs over the images of the launch.
+// ---------------------------------------------------------------------------------------------
+template <int LOGM>
+struct Panel16Geom {
+    static constexpr int T = Steps<LOGM, 4>::T;
+    static constexpr int G = T >= 256 ? 1 : 256 / T;  // panels per workgroup
+    static constexpr int THREADS = T * G;
+};
+
+template <int LOGM>
+__global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_fused16_kernel(
+    const PanelBatch pb, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const unsigned pstride,
+    const int npanels, const int ntiles, const int packed0) {
+    using St = Steps<LOGM, 4>;
+    using Geo = Panel16Geom<LOGM>;
+    constexpr int G = Geo::G, T = St::T, M = St::L, V = 16;
+    using Core = FftCore<LOGM, 4, 2, PolicyFast, 4>;
+    __shared__ float2 lds[G * 2 * St::BUF];
+    const int g = G == 1 ? 0 : (int)(threadIdx.x >> St::LOGT);
+    const int tid = threadIdx.x & (T - 1);
+    float2* grp_lds = lds + g * 2 * St::BUF;
+    // grid (ntiles, images): an integer division here would run on the VALU and drag every tile address into VGPRs
+    const int img = blockIdx.y, tl = blockIdx.x;
+    const bool active = tl * G + g < npanels;
+    const size_t tbase = (size_t)(tl * G) * pstride;
+    float2* __restrict__ data = (img == 0 ? pb.data[0] : img == 1 ? pb.data[1] : img == 2 ? pb.data[2] : pb.data[3]) + tbase;
+    const float2* __restrict__ tfilt = filt + tbase;
+    const unsigned loff = (active ? (unsigned)g : 0u) * pstride + (unsigned)tid * 4u;
+
+    typename Core::Bases bases;
+    Core::init_bases(bases, tw_fwd, tid);
+
+    // (Delaying the workgroup that landed in the odd wave slots by half a load phase, so that the two workgroups of
+    // a CU alternate between memory and LDS phases, was measured: no gain up to 5 us of delay, slower beyond.)
+    const int wgid = blockIdx.y * gridDim.x + blockIdx.x; (void)wgid;
+    FDR_STAMP(pb, wgid, 0);
+    float2 v[4][V];
+    tile_load<Core, false>(data, loff, 1u, v);
+    FDR_STAMP(pb, wgid, 1);
+#ifdef FDR_DEBUG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FDR_STAMP(pb, wgid, 2);
+#endif
+    Core::template run<0, false>(v, grp_lds, tw_fwd, bases, tid);
+    FDR_STAMP(pb, wgid, 3);
+
+    const bool packed_tile = packed0 && tl == 0;  // uniform per workgroup
+    constexpr int SEQ = Core::SLOTS;
+    if (packed_tile) {  // column 0 of panel 0 (packed DC + i Nyquist) finished on its own; see the lean kernel
+        float2* bufc = grp_lds + (SEQ & 1) * St::BUF;
+        float2* bufs = grp_lds + ((SEQ + 1) & 1) * St::BUF;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+            for (int q = 0; q < Core::RHOL; ++q) {
+                const int s = u * Core::RHOL + q;
+                const int k = Core::out_index(tid, u, q);
+                bufc[k] = v[0][s];
+                bufs[k] = tfilt[loff - (unsigned)tid * 4u + (unsigned)k * 4u];  // (read back below: no registers held)
+            }
+        __syncthreads();
+        if (g == 0) {
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int s = u * Core::RHOL + q;
+                    const int k = Core::out_index(tid, u, q);
+                    const int km = (M - k) & (M - 1);
+                    const float2 c = v[0][s], cm = bufc[km], sm = bufs[km], sl_s = bufs[k];
+                    const float2 f0 = make_float2(0.5f * (c.x + cm.x), 0.5f * (c.y - cm.y));
+                    const float2 fn = make_float2(0.5f * (c.y + cm.y), 0.5f * (cm.x - c.x));
+                    float2 a0, an;
+                    if (k == 0 || k == M / 2) { a0 = make_float2(sl_s.x, 0.f); an = make_float2(sl_s.y, 0.f); }
+                    else if (k < M / 2) { a0 = sl_s; an = sm; }
+                    else { a0 = make_float2(sm.x, -sm.y); an = make_float2(sl_s.x, -sl_s.y); }
+                    const float2 z0 = cmul_fma(f0, a0), zn = cmul_fma(fn, an);
+                    v[0][s] = make_float2(z0.x - zn.y, z0.y + zn.x);
+                }
+        }
+        __syncthreads();  // both buffers were read above
+    }
+    {
+        const bool col0_done = packed_tile && g == 0;
+        // W in pieces of PC slots, the next piece requested before the current one is used.  (Measured: requesting the
+        // first pieces before the forward transform costs 27 spilled registers and 5 us; the compiler barriers keep
+        // hipcc from hoisting all 32 loads to the top.)
+        constexpr int PC = 4;  // slots per piece: 32 VGPRs, two pieces in flight
+        auto wload = [&](int h, float2 (&w)[PC][4]) {
+#pragma unroll
+            for (int i = 0; i < PC; ++i) {
+                const int s = PC * h + i, u = s / Core::RHOL, q = s % Core::RHOL;
+                const unsigned uoff = (unsigned)(((q << Core::LOGOUT) + u * Core::T) * 4);
+                const gchar* ub = uniform_gptr(tfilt + uoff);
+                FDR_GLOAD32(ub, loff * 8u, w[i][0], w[i][1], w[i][2], w[i][3]);
+            }
+        };
+        auto wmul = [&](int h, const float2 (&w)[PC][4]) {
+#pragma unroll
+            for (int i = 0; i < PC; ++i) {
+                const int s = PC * h + i;
+                v[0][s] = cmul_fma(v[0][s], col0_done ? make_float2(1.f, 0.f) : w[i][0]);
+                v[1][s] = cmul_fma(v[1][s], w[i][1]);
+                v[2][s] = cmul_fma(v[2][s], w[i][2]);
+                v[3][s] = cmul_fma(v[3][s], w[i][3]);
+            }
+        };
+        float2 wa[PC][4], wb[PC][4];
+        wload(0, wa);
+#pragma unroll
+        for (int h = 0; h < V / PC; h += 2) {
+            asm volatile("" ::: "memory");
+            wload(h + 1, wb);
+            wmul(h, wa);
+            asm volatile("" ::: "memory");
+            if (h + 2 < V / PC) wload(h + 2, wa);
+            wmul(h + 1, wb);
+        }
+    }
+    FDR_STAMP(pb, wgid, 4);
+    if constexpr (Core::RHOL != Core::RHO0) {
+        redistribute<LOGM, Core, SEQ>(v, grp_lds, tid);
+        Core::template run<SEQ + 4, true>(v, grp_lds, tw_fwd, bases, tid);
+    } else {
+        Core::template run<SEQ, true>(v, grp_lds, tw_fwd, bases, tid);
+    }
+    FDR_STAMP(pb, wgid, 5);
+    if (active) tile_store<Core>(data, loff, v);
+    FDR_STAMP(pb, wgid, 6);
+#ifdef FDR_DEBUG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FDR_STAMP(pb, wgid, 7);
+    if (threadIdx.x == 0 && pb.stamps) pb.stamps[(size_t)wgid * 32 + 8] = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 4);
+#endif
+}
+
 template <int LOGM>
 static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const float2* tw, hipStream_t s) {
     using Geo = PanelGeom<LOGM>;
@@ -1180,10 +1365,19 @@ static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const floa
         if (pb.nimg <= 0) { pb.nimg = 1; pb.data[0] = a.data; }
         for (int k = pb.nimg; k < 4; ++k) pb.data[k] = pb.data[0];
         const int total = ntiles * pb.nimg;
+        if constexpr (LOGM >= 10) {
+            if (a.v16) {  // 16 values per thread, two 256-thread workgroups per CU
+                using G16 = Panel16Geom<LOGM>;
+                const int nt16 = (npanels + G16::G - 1) / G16::G;
+                hipLaunchKernelGGL((fft_cols_panel_fused16_kernel<LOGM>), dim3(nt16, pb.nimg), dim3(G16::THREADS), 0, s, pb, a.filt,
+                                   tw, (unsigned)ps, npanels, nt16, a.packed0);
+                return hipGetLastError();
+            }
+        }
         // single register set, one workgroup per tile, two workgroups per CU: always for 8192-point columns (1024
         // threads per transform leave no room for a second set), on request (FDR_FLAG_LEAN_COLS) otherwise
         if (Geo::THREADS >= 1024 || a.lean) {
-            hipLaunchKernelGGL((fft_cols_panel_fused_lean_kernel<LOGM>), dim3(total), dim3(Geo::THREADS), 0, s, pb, a.filt, tw,
+            hipLaunchKernelGGL((fft_cols_panel_fused_lean_kernel<LOGM>), dim3(ntiles, pb.nimg), dim3(Geo::THREADS), 0, s, pb, a.filt, tw,
                                (unsigned)ps, npanels, ntiles, a.packed0);
             return hipGetLastError();
         }

@@ -187,7 +187,7 @@ def test_committed_vectors_on_gpu(fdr):
 # ------------------------------------------------------------------------------------------------
 # fast-mode variants, batched mode, large sizes
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("flags_name", ["FLAG_ROWMAJOR", "FLAG_NO_PACKING", "FLAG_NO_PIPELINE", "FLAG_POW2_PANELS", "FLAG_SIMPLE_PATH", "FLAG_LEAN_COLS", "FLAG_FULL_SPECTRUM"])
+@pytest.mark.parametrize("flags_name", ["FLAG_ROWMAJOR", "FLAG_NO_PACKING", "FLAG_NO_PIPELINE", "FLAG_POW2_PANELS", "FLAG_SIMPLE_PATH", "FLAG_LEAN_COLS", "FLAG_FULL_SPECTRUM", "FLAG_COLS8"])
 @pytest.mark.parametrize("shape", [(200, 300), (1024, 1024)])
 def test_fast_variants_within_tolerance(fdr, oracle, flags_name, shape):
     psf = oracle.motion_blur_kernel(50, 30.0)
@@ -216,6 +216,21 @@ def test_fused_normalise_pass_equals_two_pass(fdr, oracle, shape, spin_limit, mo
         for area in (fdr.NORM_PADDED, fdr.NORM_CROPPED):
             for _ in range(2):  # second call: the granules of the first launch (older epoch) must not satisfy the wait
                 _assert_same(p.wiener(img, norm_area=area), q.wiener(img, norm_area=area), "fused vs two-pass, area %d" % area)
+
+
+@pytest.mark.parametrize("shape", [(1024, 64), (2000, 100), (4096, 128), (8192, 64), (1024, 1024)])
+def test_cols16_kernel_within_tolerance(fdr, oracle, shape):
+    """Pass B' with 16 values per thread (radix-16 steps) against the oracle and against the radix-8 kernel."""
+    psf = oracle.motion_blur_kernel(15, 30.0)
+    img = _image(oracle, shape[0], shape[1], 0x5EED0002)
+    ref = oracle.serial_channel(img, psf, 0.01)
+    M, N = fdr.nextPowerOfTwo(shape[0]), fdr.nextPowerOfTwo(shape[1])
+    with fdr.Plan(M, N, fdr.MODE_FAST) as p, fdr.Plan(M, N, fdr.MODE_FAST, flags=fdr.FLAG_COLS8) as q:
+        p.set_psf(psf, 0.01)
+        q.set_psf(psf, 0.01)
+        got, base = p.wiener(img), q.wiener(img)
+    assert np.abs(got - ref).max() <= TOL and np.linalg.norm(got - ref) / np.linalg.norm(ref) <= TOL
+    assert np.abs(got - base).max() <= TOL
 
 
 def test_psf_generated_on_device_into_the_plan(fdr, oracle):
