@@ -19,6 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PASS_OF = {
     "fft_rows4_fwd_packed_kernel": "A rows: pad+FFT (real->complex)",
     "fft_cols_panel_fused_kernel": "B' cols: FFT*W*IFFT",
+    "fft_cols_panel_fused16_kernel": "B' cols: FFT*W*IFFT",
+    "fft_cols_panel_fused_lean_kernel": "B' cols: FFT*W*IFFT",
     "fft_rows4_inv_packed_kernel": "C' rows: IFFT+real+minmax",
     "normalize_kernel": "E normalize+crop",
 }
