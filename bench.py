@@ -54,9 +54,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=4096, help="synthetic image edge (power of two)")
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=18, help="images per GPU per step")
     ap.add_argument("--mode", choices=["fast", "parity"], default="fast")
-    ap.add_argument("--streams", type=int, default=2, help="internal streams / workspaces the batch alternates over")
+    ap.add_argument("--streams", type=int, default=3, help="internal streams / workspaces the batch alternates over")
     ap.add_argument("--group", type=int, default=0, help="images per pass-B' launch (fast mode; 1..4, streams*group <= 8; 0 = 4 up to 2048^2, else 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=0, help="edge of the CPU-baseline sample (default: --size, capped at 4096)")
@@ -160,8 +160,8 @@ def main():
         images = world * B * args.steps
         value = images * P / 1e6 / elapsed
         # bytes per pixel of the passes that actually ran (the fused C'E pass drops the raw-plane round trip)
-        pipe_bpp = sum(PASS_BYTES[spectrum].get(n.rsplit(" [", 1)[0] if n.endswith(" images]") else n, 0) for n, _, _ in passes) \
-            or PIPELINE_BYTES[(args.mode, spectrum)]
+        base_names = {n.rsplit(" [", 1)[0] if n.endswith(" images]") else n for n, _, _ in passes}
+        pipe_bpp = sum(PASS_BYTES[spectrum].get(n, 0) for n in base_names) or PIPELINE_BYTES[(args.mode, spectrum)]
         pipe_gbps = pipe_bpp * P * images / elapsed / 1e9
         dom = max(passes, key=lambda t: t[1]) if passes else None  # longest launch
         roofline = None

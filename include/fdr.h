@@ -155,7 +155,7 @@ int fdr_synth_image_dev(int device, uint64_t seed, uint64_t first_index, size_t 
  *    With profiling on, every fdr_wiener_*_dev call records a hipEvent pair around each
  *    kernel on the call's stream; fdr_plan_pass_times synchronises and returns the mean
  *    duration in ms of each pass since the last reset, names[i] a static string.         */
-#define FDR_MAX_PASSES 8
+#define FDR_MAX_PASSES 16
 int fdr_plan_profile(fdr_plan* plan, int enable);
 int fdr_plan_pass_times(fdr_plan* plan, int* n_passes, float* mean_ms, const char** names, int* launches);
 

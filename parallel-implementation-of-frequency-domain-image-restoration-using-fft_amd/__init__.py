@@ -31,7 +31,7 @@ FLAG_FUSED_NORM = 128
 FLAG_COLS8 = 256
 NORM_PADDED = 1
 NORM_CROPPED = 0
-MAX_PASSES = 8
+MAX_PASSES = 16
 
 _f32p = ctypes.POINTER(ctypes.c_float)
 

@@ -172,6 +172,11 @@ const char* const kPassColsFused = "B' cols: FFT*W*IFFT";
 const char* const kPassColsFusedN[5] = {nullptr, kPassColsFused, "B' cols: FFT*W*IFFT [2 images]", "B' cols: FFT*W*IFFT [3 images]",
                                        "B' cols: FFT*W*IFFT [4 images]"};
 const char* const kPassRowsInvReal = "C' rows: IFFT+real+minmax";
+const char* const kPassRowsFwdN[5] = {nullptr, nullptr, "A rows: pad+FFT (real->complex) [2 images]", "A rows: pad+FFT (real->complex) [3 images]",
+                                     "A rows: pad+FFT (real->complex) [4 images]"};
+const char* const kPassRowsInvRealN[5] = {nullptr, nullptr, "C' rows: IFFT+real+minmax [2 images]", "C' rows: IFFT+real+minmax [3 images]",
+                                         "C' rows: IFFT+real+minmax [4 images]"};
+const char* const kPassNormalizeN[5] = {nullptr, nullptr, "E normalize+crop [2 images]", "E normalize+crop [3 images]", "E normalize+crop [4 images]"};
 const char* const kPassNormalize = "E normalize+crop";
 const char* const kPassRowsInvNorm = "C'E rows: IFFT+minmax+normalize+crop (fused)";
 const char* const kPassFixup = "E' fixup (no-op unless a wait timed out)";
@@ -329,6 +334,48 @@ int panel_stage_CE(fdr_plan* p, fdr_plan::Slot& w, int rows, int cols, float* d_
         const int n_part = rows4_minmax_partials(p->logN, p->M);
         if (n_part <= 0 || n_part > p->mm_part_cap || n_part > 4096) return fail(FDR_ERR_STATE, "fdr_wiener: min/max partial count out of range");
         FDR_HIP(launch_normalize(w.raw, p->N, w.mm_part, n_part, nullptr, d_out, rows, cols, out_stride, s));
+    }
+    return FDR_OK;
+}
+
+// the same passes for a GROUP of 2..4 images in one launch each (blockIdx.y = image); packed half-spectrum path only
+bool can_batch_rows(const fdr_plan* p) { return p->half && !p->no_packing && !p->fused_norm; }
+int panel_stage_A_batch(fdr_plan* p, fdr_plan::Slot* const* ws, int n, const float* const* d_imgs, int rows, int cols, int stride,
+                        hipStream_t s) {
+    ScopedPass t(p, s, kPassRowsFwdN[n]);
+    RowArgs a{};
+    a.src_real = d_imgs[0]; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
+    a.dst_c = ws[0]->work; a.M = p->M; a.no_packing = 0; a.pstride = p->pstride; a.half = 1;
+    a.batch.nimg = n;
+    for (int k = 0; k < 4; ++k) { a.batch.src_real[k] = d_imgs[k < n ? k : 0]; a.batch.spec[k] = ws[k < n ? k : 0]->work; }
+    FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
+    return FDR_OK;
+}
+int panel_stage_CE_batch(fdr_plan* p, fdr_plan::Slot* const* ws, int n, int rows, int cols, float* const* d_outs, int out_stride,
+                         int mm_rows, int mm_cols, hipStream_t s) {
+    {
+        ScopedPass t(p, s, kPassRowsInvRealN[n]);
+        RowArgs a{};
+        a.src_c = ws[0]->work; a.dst_real = ws[0]->raw; a.mm_part = ws[0]->mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
+        a.no_packing = 0; a.pstride = p->pstride; a.half = 1;
+        a.batch.nimg = n;
+        for (int k = 0; k < 4; ++k) {
+            const fdr_plan::Slot* w = ws[k < n ? k : 0];
+            a.batch.spec[k] = w->work; a.batch.raw[k] = w->raw; a.batch.mm_part[k] = w->mm_part;
+        }
+        FDR_HIP(launch_rows4(p->logN, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, a, p->tw_row_f, s));
+    }
+    {
+        ScopedPass t(p, s, kPassNormalizeN[n]);
+        const int n_part = rows4_minmax_partials(p->logN, p->M);
+        if (n_part <= 0 || n_part > p->mm_part_cap || n_part > 4096) return fail(FDR_ERR_STATE, "fdr_wiener: min/max partial count out of range");
+        NormBatch nb{};
+        nb.nimg = n;
+        for (int k = 0; k < 4; ++k) {
+            const fdr_plan::Slot* w = ws[k < n ? k : 0];
+            nb.raw[k] = w->raw; nb.part[k] = w->mm_part; nb.out[k] = d_outs[k < n ? k : 0];
+        }
+        FDR_HIP(launch_normalize(ws[0]->raw, p->N, ws[0]->mm_part, n_part, nullptr, d_outs[0], rows, cols, out_stride, s, &nb));
     }
     return FDR_OK;
 }
@@ -623,6 +670,15 @@ int fdr_wiener_batch_f32_dev(fdr_plan* p, const float* d_imgs, size_t img_pitch,
         if (!p->panel) {
             rc = wiener_dev_impl(p, *ws[0], d_imgs + (size_t)i0 * img_pitch, rows, cols, stride, d_out + (size_t)i0 * out_pitch,
                                  out_stride, norm_area, s);
+            if (rc != FDR_OK) return rc;
+            continue;
+        }
+        if (n > 1 && can_batch_rows(p)) {  // every pass once for the whole group
+            const float* ins[4]; float* outs[4];
+            for (int k = 0; k < n; ++k) { ins[k] = d_imgs + (size_t)(i0 + k) * img_pitch; outs[k] = d_out + (size_t)(i0 + k) * out_pitch; }
+            rc = panel_stage_A_batch(p, ws, n, ins, rows, cols, stride, s);
+            if (rc == FDR_OK) rc = panel_stage_B(p, ws, n, s);
+            if (rc == FDR_OK) rc = panel_stage_CE_batch(p, ws, n, rows, cols, outs, out_stride, mm_rows, mm_cols, s);
             if (rc != FDR_OK) return rc;
             continue;
         }

@@ -240,7 +240,13 @@ hipError_t launch_reduce_minmax(const float2* mm_part, int n_part, float* mm, hi
 template <bool VEC4>
 __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ raw, int N, const float2* __restrict__ part,
                                                         int n_part, const float* __restrict__ mm, float* __restrict__ out,
-                                                        int rows, int cols, int out_stride) {
+                                                        int rows, int cols, int out_stride, const NormBatch nb) {
+    if (nb.nimg > 1) {  // blockIdx.y = image
+        const int i = blockIdx.y;
+        raw = i == 0 ? nb.raw[0] : i == 1 ? nb.raw[1] : i == 2 ? nb.raw[2] : nb.raw[3];
+        part = i == 0 ? nb.part[0] : i == 1 ? nb.part[1] : i == 2 ? nb.part[2] : nb.part[3];
+        out = i == 0 ? nb.out[0] : i == 1 ? nb.out[1] : i == 2 ? nb.out[2] : nb.out[3];
+    }
     __shared__ float2 red[4];
     float mn, mx;
     if (part != nullptr) {
@@ -289,17 +295,22 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict_
 }
 
 hipError_t launch_normalize(const float* raw, int N, const float2* mm_part, int n_part, const float* mm, float* out,
-                            int rows, int cols, int out_stride, hipStream_t s) {
+                            int rows, int cols, int out_stride, hipStream_t s, const NormBatch* batch) {
+    NormBatch nb{};
+    if (batch) nb = *batch;
+    const int ny = nb.nimg > 1 ? nb.nimg : 1;
     if (rows <= 0 || cols <= 0) return hipSuccess;
-    const bool vec4 = (cols % 4 == 0) && (out_stride % 4 == 0) && (N % 4 == 0) &&
-                      ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && ((reinterpret_cast<uintptr_t>(raw) & 15) == 0);
+    bool vec4 = (cols % 4 == 0) && (out_stride % 4 == 0) && (N % 4 == 0) &&
+                ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && ((reinterpret_cast<uintptr_t>(raw) & 15) == 0);
+    for (int k = 0; k < nb.nimg; ++k)
+        vec4 = vec4 && ((reinterpret_cast<uintptr_t>(nb.out[k]) & 15) == 0) && ((reinterpret_cast<uintptr_t>(nb.raw[k]) & 15) == 0);
     const int W = vec4 ? 1024 : 256;
     long long nseg = (long long)rows * ((cols + W - 1) / W);
     int grid = nseg > 2048 ? 2048 : (int)nseg;
     if (vec4)
-        hipLaunchKernelGGL(normalize_kernel<true>, dim3(grid), dim3(256), 0, s, raw, N, mm_part, n_part, mm, out, rows, cols, out_stride);
+        hipLaunchKernelGGL(normalize_kernel<true>, dim3(grid, ny), dim3(256), 0, s, raw, N, mm_part, n_part, mm, out, rows, cols, out_stride, nb);
     else
-        hipLaunchKernelGGL(normalize_kernel<false>, dim3(grid), dim3(256), 0, s, raw, N, mm_part, n_part, mm, out, rows, cols, out_stride);
+        hipLaunchKernelGGL(normalize_kernel<false>, dim3(grid, ny), dim3(256), 0, s, raw, N, mm_part, n_part, mm, out, rows, cols, out_stride, nb);
     return hipGetLastError();
 }
 

@@ -364,7 +364,7 @@ struct FftCore {
 // small kernel reduces the partials (deterministic, and no same-address atomics: 65k atomics on
 // two words cost ~0.7 ms on MI355X, 15x the kernel that issued them).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void block_minmax_store(float mn, float mx, float2* __restrict__ part) {
+__device__ __forceinline__ void block_minmax_store(float mn, float mx, float2* __restrict__ part, int index = -1) {
     __shared__ float2 red[16];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -379,7 +379,7 @@ __device__ __forceinline__ void block_minmax_store(float mn, float mx, float2* _
             mn = fminf(mn, red[w].x);
             mx = fmaxf(mx, red[w].y);
         }
-        const int b = blockIdx.x + gridDim.x * blockIdx.y;
+        const int b = index >= 0 ? index : (int)(blockIdx.x + gridDim.x * blockIdx.y);
         part[b] = make_float2(mn, mx);  // (+inf, -inf) when the block saw no counted element
     }
 }

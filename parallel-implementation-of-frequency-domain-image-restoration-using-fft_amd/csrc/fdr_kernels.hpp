@@ -17,6 +17,22 @@ enum ColKind {
     COL_FUSED = 4        // fast pass B': forward column FFT, multiply by W, inverse column FFT
 };
 
+// several images per launch of the fast row passes / the normalisation (blockIdx.y = image): small images are launch
+// bound, one launch per pass and GROUP of images fills the chip.  nimg <= 1: the single-image fields are used.
+struct RowBatch {
+    const float* src_real[4];  // pass A input
+    float2* spec[4];           // pass A output / pass C' input (panel-major spectrum)
+    float* raw[4];             // pass C' output
+    float2* mm_part[4];        // pass C' min/max partials
+    int nimg;
+};
+struct NormBatch {
+    const float* raw[4];
+    const float2* part[4];
+    float* out[4];
+    int nimg;
+};
+
 struct RowArgs {
     // input
     const float* src_real;  // ROW_IN_REAL: rows x cols image, zero-padded on the fly to M x L
@@ -31,6 +47,7 @@ struct RowArgs {
     size_t pstride;     // rows4 kernels: panel stride of the panel-major spectrum, in float2 elements
     int half;           // rows4 packed kernels: half (Hermitian) spectrum, N/8 + 1 panels
     int no_packing;     // rows4 kernels: one complex transform per row instead of two rows per transform
+    RowBatch batch;     // rows4 packed kernels: several images per launch
 };
 
 // Fused pass C'+E (rows inverse + min/max + normalise + crop in ONE launch, fast panel path, images whose real plane
@@ -111,7 +128,7 @@ int rows_minmax_partials(int logl, int M);
 int cols_minmax_partials(int logm, int N);
 // mm_part != nullptr: every workgroup folds the n_part partials itself; else mm = {min, max} from launch_reduce_minmax
 hipError_t launch_normalize(const float* raw, int N, const float2* mm_part, int n_part, const float* mm, float* out,
-                            int rows, int cols, int out_stride, hipStream_t s);
+                            int rows, int cols, int out_stride, hipStream_t s, const NormBatch* batch = nullptr);
 hipError_t launch_psf_motion(int size, double angle_deg, float* d_out, hipStream_t s);
 hipError_t launch_synth(uint64_t seed, uint64_t first, size_t count, float* d_out, hipStream_t s);
 hipError_t launch_dft_naive(const float2* src, float2* dst, int n, int inverse, hipStream_t s);

@@ -131,12 +131,22 @@ struct Rows4PackGeom {
     static constexpr int THREADS = T * G;
 };
 
+template <class P>
+__device__ __forceinline__ P pick4(P const (&p)[4], int i) {  // select chain: a dynamic index would send the kernarg array to scratch
+    return i == 0 ? p[0] : i == 1 ? p[1] : i == 2 ? p[2] : p[3];
+}
+
 // HALF: keep only the non-redundant half of each Hermitian row spectrum -- columns 0 .. N/2-1 in panels
 // 0 .. N/8-1.  X[m,0] and X[m,N/2] are real for a real row, so the Nyquist column rides in the imaginary
 // part of column 0: stored(m, 0) = X[m,0] + i X[m,N/2]  ("packed column", undone in passes B' and C').
 template <int LOGL, bool HALF>
-__global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_packed_kernel(const RowArgs a,
+__global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_packed_kernel(const RowArgs a0,
                                                                                           const float2* __restrict__ tw_fwd) {
+    RowArgs a = a0;
+    if (a0.batch.nimg > 1) {  // blockIdx.y = image
+        a.src_real = pick4(a0.batch.src_real, blockIdx.y);
+        a.dst_c = pick4(a0.batch.spec, blockIdx.y);
+    }
     using St = Steps<LOGL>;
     using Geo = Rows4PackGeom<LOGL>;
     constexpr int G = Geo::G, T = St::T, L = St::L;
@@ -344,8 +354,14 @@ __device__ __forceinline__ void rows4_pack(int tid, const float2 (&y)[4][8], flo
 // kernel); the upper half is rebuilt on load as the conjugate of the mirrored column (every stored line is
 // touched twice by the same workgroup, the second time from L1/L2).
 template <int LOGL, bool HALF>
-__global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_packed_kernel(const RowArgs a,
+__global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_packed_kernel(const RowArgs a0,
                                                                                           const float2* __restrict__ tw_fwd) {
+    RowArgs a = a0;
+    if (a0.batch.nimg > 1) {  // blockIdx.y = image
+        a.src_c = pick4(a0.batch.spec, blockIdx.y);
+        a.dst_real = pick4(a0.batch.raw, blockIdx.y);
+        a.mm_part = pick4(a0.batch.mm_part, blockIdx.y);
+    }
     using St = Steps<LOGL>;
     using Geo = Rows4PackGeom<LOGL>;
     constexpr int G = Geo::G, T = St::T, L = St::L;
@@ -407,7 +423,7 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_pa
                 }
         }
     }
-    block_minmax_store(mn, mx, a.mm_part);
+    block_minmax_store(mn, mx, a.mm_part, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -656,7 +672,7 @@ template <int LOGL>
 static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const float2* tw, hipStream_t s) {
     using Geo = Rows4Geom<LOGL>;
     const int groups = (a.M + 3) / 4;
-    const dim3 grid((groups + Geo::G - 1) / Geo::G), block(Geo::THREADS);
+    const dim3 grid((groups + Geo::G - 1) / Geo::G, a.batch.nimg > 1 && !a.no_packing ? a.batch.nimg : 1), block(Geo::THREADS);
     static_assert(Rows4PackGeom<LOGL>::G == Geo::G && Rows4PackGeom<LOGL>::THREADS == Geo::THREADS, "same launch shape");
     if (in == ROW_IN_REAL && out == ROW_OUT_COMPLEX) {
         if (a.no_packing) hipLaunchKernelGGL((fft_rows4_kernel<LOGL, ROW_IN_REAL, ROW_OUT_COMPLEX, false>), grid, block, 0, s, a, tw);
