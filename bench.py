@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=4096, help="synthetic image edge (power of two)")
-    ap.add_argument("--batch", type=int, default=18, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=24, help="images per GPU per step")
     ap.add_argument("--mode", choices=["fast", "parity"], default="fast")
     ap.add_argument("--streams", type=int, default=3, help="internal streams / workspaces the batch alternates over")
     ap.add_argument("--group", type=int, default=0, help="images per pass-B' launch (fast mode; 1..4, streams*group <= 8; 0 = 4 up to 2048^2, else 1)")
