@@ -126,6 +126,18 @@ int fdr_wiener_batch_f32_dev(fdr_plan* plan, const float* d_imgs, size_t img_pit
                              int rows, int cols, int stride,
                              float* d_out, size_t out_pitch, int out_stride, int norm_area, void* stream);
 
+/* Host-pointer batch: `count` images at imgs_host + i*img_pitch, results to out_host + i*out_pitch (elements).
+ * H2D copy, restoration and D2H copy of consecutive images overlap on three internal streams with three images in
+ * flight -- the pinned-buffer / cudaMemcpyAsync pipeline fft/fft_gpu.cu:306-350,372-385 sets out to build.  Buffers
+ * from fdr_host_alloc (pinned; replaces cudaMallocHost, fft/fft_gpu.cu:306-308) are copied by DMA in place and the
+ * three stages overlap; pageable buffers work too, at the rate of the synchronous copies the runtime then makes.
+ * Synchronous: returns when every result is in out_host.                                                        */
+int fdr_host_alloc(size_t bytes, void** out);
+int fdr_host_free(void* p);
+int fdr_wiener_batch_f32(fdr_plan* plan, const float* imgs_host, size_t img_pitch, int count,
+                         int rows, int cols, int stride,
+                         float* out_host, size_t out_pitch, int out_stride, int norm_area);
+
 /* Batched mode only: let consecutive images of fdr_wiener_batch_f32_dev alternate over `nstreams`
  * (1..4) private workspaces on internal HIP streams, forked from / joined to the caller's stream,
  * so one image's kernel tails overlap the next image's kernel heads.  Costs (nstreams-1) extra

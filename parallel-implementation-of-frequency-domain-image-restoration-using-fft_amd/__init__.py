@@ -84,6 +84,9 @@ def _load():
     L.fdr_wiener_f32.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci]
     L.fdr_wiener_f32_dev.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, vp]
     L.fdr_wiener_batch_f32_dev.argtypes = [vp, vp, ctypes.c_size_t, ci, ci, ci, ci, vp, ctypes.c_size_t, ci, ci, vp]
+    L.fdr_wiener_batch_f32.argtypes = [vp, vp, ctypes.c_size_t, ci, ci, ci, ci, vp, ctypes.c_size_t, ci, ci]
+    L.fdr_host_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+    L.fdr_host_free.argtypes = [vp]
     L.fdr_plan_set_concurrency.argtypes = [vp, ci]
     L.fdr_plan_set_batching.argtypes = [vp, ci, ci]
     L.fdr_fft2d_c2c.argtypes = [vp, vp, ci]
@@ -95,7 +98,8 @@ def _load():
     L.fdr_plan_pass_times.argtypes = [vp, ctypes.POINTER(ci), _f32p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ci)]
     for name in ("fdr_device_count", "fdr_next_pow2", "fdr_is_pow2", "fdr_plan_create", "fdr_plan_destroy", "fdr_plan_dims",
                  "fdr_psf_motion", "fdr_psf_motion_dev", "fdr_set_psf", "fdr_set_psf_dev", "fdr_set_psf_motion",
-                 "fdr_wiener_f32", "fdr_wiener_f32_dev", "fdr_wiener_batch_f32_dev", "fdr_plan_set_concurrency", "fdr_plan_set_batching",
+                 "fdr_wiener_f32", "fdr_wiener_f32_dev", "fdr_wiener_batch_f32_dev", "fdr_wiener_batch_f32", "fdr_host_alloc", "fdr_host_free",
+                 "fdr_plan_set_concurrency", "fdr_plan_set_batching",
                  "fdr_fft2d_c2c", "fdr_fft2d_c2c_dev", "fdr_fft1d_c2c", "fdr_dft_naive_c2c", "fdr_synth_image_dev", "fdr_plan_profile", "fdr_plan_pass_times"):
         getattr(L, name).restype = ci
     return L
@@ -106,7 +110,8 @@ lib = _load()
 EXPORTED_SYMBOLS = (
     "fdr_version", "fdr_last_error", "fdr_device_count", "fdr_next_pow2", "fdr_is_pow2", "fdr_plan_create",
     "fdr_plan_destroy", "fdr_plan_dims", "fdr_psf_motion", "fdr_psf_motion_dev", "fdr_set_psf", "fdr_set_psf_dev",
-    "fdr_set_psf_motion", "fdr_wiener_f32", "fdr_wiener_f32_dev", "fdr_wiener_batch_f32_dev", "fdr_plan_set_concurrency",
+    "fdr_set_psf_motion", "fdr_wiener_f32", "fdr_wiener_f32_dev", "fdr_wiener_batch_f32_dev", "fdr_wiener_batch_f32",
+    "fdr_host_alloc", "fdr_host_free", "fdr_plan_set_concurrency",
     "fdr_plan_set_batching", "fdr_fft2d_c2c",
     "fdr_fft2d_c2c_dev", "fdr_fft1d_c2c", "fdr_dft_naive_c2c", "fdr_synth_image_dev", "fdr_plan_profile",
     "fdr_plan_pass_times")
@@ -212,6 +217,16 @@ class Plan:
                                             ctypes.c_void_p(int(d_out)), out_pitch, out_stride, int(norm_area),
                                             _stream(stream)))
 
+    def wiener_batch(self, imgs, out=None, norm_area=NORM_PADDED):
+        """Host arrays [count, rows, cols] in, restored planes out; H2D / compute / D2H of consecutive images
+        overlap (pinned arrays from host_alloc() are copied by DMA in place)."""
+        imgs = np.ascontiguousarray(imgs, dtype=np.float32)  # (no copy when it already is: pinned arrays stay pinned)
+        if out is None:
+            out = np.empty_like(imgs)
+        cnt, rows, cols = imgs.shape
+        _check(lib.fdr_wiener_batch_f32(self._h, _ptr(imgs), rows * cols, cnt, rows, cols, cols, _ptr(out), rows * cols, cols, int(norm_area)))
+        return out
+
     def set_concurrency(self, nstreams):
         """Batched mode: alternate images over `nstreams` private workspaces / internal streams."""
         _check(lib.fdr_plan_set_concurrency(self._h, int(nstreams)))
@@ -264,6 +279,18 @@ def synth_image_dev(d_out, count, seed, first_index=0, device=0, stream=None):
 
 
 # ---- fft/fft.hpp mirrors (fft_gpu namespace) --------------------------------------------------
+def host_alloc(shape, dtype=np.float32):
+    """numpy array in pinned host memory (fdr_host_alloc; the reference's cudaMallocHost buffers,
+    fft/fft_gpu.cu:306-308).  Freed when the array (and every view of it) is garbage collected."""
+    import weakref
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = ctypes.c_void_p()
+    _check(lib.fdr_host_alloc(n, ctypes.byref(p)))
+    buf = (ctypes.c_char * n).from_address(p.value)
+    weakref.finalize(buf, lib.fdr_host_free, ctypes.c_void_p(p.value))
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
 def wienerDeblur_myfft(img, psf, K, mode=MODE_PARITY, device=0, norm_area=NORM_PADDED):
     """fft_gpu::wienerDeblur_myfft(img, psf, K): one channel, pads to powers of two on the device."""
     img = np.asarray(img, dtype=np.float32)
