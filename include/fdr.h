@@ -160,6 +160,16 @@ int fdr_fft2d_c2c_dev(fdr_plan* plan, float* d_data, int inverse, void* stream);
 int fdr_fft1d_c2c(float* data_host, int n, int inverse, int mode);
 int fdr_dft_naive_c2c(float* data_host, int n, int inverse);
 
+/* -- colour epilogue of the drivers (serial.cpp:43-54, gpu.cpp:123-137; utils.hpp:55-71 applyWhiteBalance) on the
+ *    device: restored planes B, G, R in [0,1] -> Lab -> L scaled so that its mean matches the blurred input's, clamped
+ *    to [0,100] -> BGR -> 8 bit interleaved (convertTo(CV_8U, 255)).  Planes: rows x cols, row stride `stride`
+ *    (elements); out: rows x cols x 3 bytes, row stride `out_stride_bytes`.  The Lab formulae are OpenCV's (third
+ *    party, version unpinned by the reference): expect +-1 at 8 bit against a given OpenCV build.               */
+int fdr_white_balance_u8_dev(int device, const float* const d_orig_bgr[3], const float* const d_restored_bgr[3],
+                             int rows, int cols, int stride, unsigned char* d_out_bgr8, int out_stride_bytes, void* stream);
+int fdr_white_balance_u8(int device, const float* const orig_bgr[3], const float* const restored_bgr[3],
+                         int rows, int cols, int stride, unsigned char* out_bgr8, int out_stride_bytes);
+
 /* -- synthetic input: pixel i = top 24 bits of splitmix64(seed+first+i) / 2^24 */
 int fdr_synth_image_dev(int device, uint64_t seed, uint64_t first_index, size_t count, float* d_out, void* stream);
 

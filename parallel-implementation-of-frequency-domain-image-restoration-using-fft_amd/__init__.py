@@ -87,6 +87,8 @@ def _load():
     L.fdr_wiener_batch_f32.argtypes = [vp, vp, ctypes.c_size_t, ci, ci, ci, ci, vp, ctypes.c_size_t, ci, ci]
     L.fdr_host_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
     L.fdr_host_free.argtypes = [vp]
+    L.fdr_white_balance_u8.argtypes = [ci, ctypes.POINTER(vp), ctypes.POINTER(vp), ci, ci, ci, vp, ci]
+    L.fdr_white_balance_u8_dev.argtypes = [ci, ctypes.POINTER(vp), ctypes.POINTER(vp), ci, ci, ci, vp, ci, vp]
     L.fdr_plan_set_concurrency.argtypes = [vp, ci]
     L.fdr_plan_set_batching.argtypes = [vp, ci, ci]
     L.fdr_fft2d_c2c.argtypes = [vp, vp, ci]
@@ -99,7 +101,7 @@ def _load():
     for name in ("fdr_device_count", "fdr_next_pow2", "fdr_is_pow2", "fdr_plan_create", "fdr_plan_destroy", "fdr_plan_dims",
                  "fdr_psf_motion", "fdr_psf_motion_dev", "fdr_set_psf", "fdr_set_psf_dev", "fdr_set_psf_motion",
                  "fdr_wiener_f32", "fdr_wiener_f32_dev", "fdr_wiener_batch_f32_dev", "fdr_wiener_batch_f32", "fdr_host_alloc", "fdr_host_free",
-                 "fdr_plan_set_concurrency", "fdr_plan_set_batching",
+                 "fdr_white_balance_u8", "fdr_white_balance_u8_dev", "fdr_plan_set_concurrency", "fdr_plan_set_batching",
                  "fdr_fft2d_c2c", "fdr_fft2d_c2c_dev", "fdr_fft1d_c2c", "fdr_dft_naive_c2c", "fdr_synth_image_dev", "fdr_plan_profile", "fdr_plan_pass_times"):
         getattr(L, name).restype = ci
     return L
@@ -111,7 +113,7 @@ EXPORTED_SYMBOLS = (
     "fdr_version", "fdr_last_error", "fdr_device_count", "fdr_next_pow2", "fdr_is_pow2", "fdr_plan_create",
     "fdr_plan_destroy", "fdr_plan_dims", "fdr_psf_motion", "fdr_psf_motion_dev", "fdr_set_psf", "fdr_set_psf_dev",
     "fdr_set_psf_motion", "fdr_wiener_f32", "fdr_wiener_f32_dev", "fdr_wiener_batch_f32_dev", "fdr_wiener_batch_f32",
-    "fdr_host_alloc", "fdr_host_free", "fdr_plan_set_concurrency",
+    "fdr_host_alloc", "fdr_host_free", "fdr_white_balance_u8", "fdr_white_balance_u8_dev", "fdr_plan_set_concurrency",
     "fdr_plan_set_batching", "fdr_fft2d_c2c",
     "fdr_fft2d_c2c_dev", "fdr_fft1d_c2c", "fdr_dft_naive_c2c", "fdr_synth_image_dev", "fdr_plan_profile",
     "fdr_plan_pass_times")
@@ -279,6 +281,19 @@ def synth_image_dev(d_out, count, seed, first_index=0, device=0, stream=None):
 
 
 # ---- fft/fft.hpp mirrors (fft_gpu namespace) --------------------------------------------------
+def applyWhiteBalance_u8(orig_bgr, restored_bgr, device=0):
+    """The drivers' colour epilogue (serial.cpp:43-54 / gpu.cpp:123-137 with utils.hpp:55-71) on the device:
+    two lists of three float planes (B, G, R in [0,1]) -> uint8 [rows, cols, 3] BGR."""
+    o = [np.ascontiguousarray(c, dtype=np.float32) for c in orig_bgr]
+    r = [np.ascontiguousarray(c, dtype=np.float32) for c in restored_bgr]
+    rows, cols = o[0].shape
+    out = np.empty((rows, cols, 3), dtype=np.uint8)
+    po = (ctypes.c_void_p * 3)(*[c.ctypes.data for c in o])
+    pr = (ctypes.c_void_p * 3)(*[c.ctypes.data for c in r])
+    _check(lib.fdr_white_balance_u8(int(device), po, pr, rows, cols, cols, ctypes.c_void_p(out.ctypes.data), 3 * cols))
+    return out
+
+
 def host_alloc(shape, dtype=np.float32):
     """numpy array in pinned host memory (fdr_host_alloc; the reference's cudaMallocHost buffers,
     fft/fft_gpu.cu:306-308).  Freed when the array (and every view of it) is garbage collected."""

@@ -891,6 +891,54 @@ int fdr_fft1d_c2c(float* data_host, int n, int inverse, int mode) {
     return FDR_OK;
 }
 
+int fdr_white_balance_u8_dev(int device, const float* const d_orig_bgr[3], const float* const d_restored_bgr[3], int rows,
+                             int cols, int stride, unsigned char* d_out_bgr8, int out_stride_bytes, void* stream) {
+    if (!d_orig_bgr || !d_restored_bgr || !d_out_bgr8) return fail(FDR_ERR_ARG, "fdr_white_balance_u8_dev: null argument");
+    if (rows <= 0 || cols <= 0 || stride < cols || out_stride_bytes < 3 * cols) return fail(FDR_ERR_ARG, "fdr_white_balance_u8_dev: bad shape");
+    ColorArgs a{};
+    for (int c = 0; c < 3; ++c) {
+        if (!d_orig_bgr[c] || !d_restored_bgr[c]) return fail(FDR_ERR_ARG, "fdr_white_balance_u8_dev: null plane");
+        a.orig[c] = d_orig_bgr[c]; a.rest[c] = d_restored_bgr[c];
+    }
+    a.rows = rows; a.cols = cols; a.stride = stride; a.out = d_out_bgr8; a.out_stride = out_stride_bytes;
+    FDR_HIP(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    double2* part = nullptr;
+    FDR_HIP(hipMallocAsync((void**)&part, (size_t)color_partials(rows, cols) * sizeof(double2), s));
+    hipError_t e = launch_color_epilogue(a, part, s);
+    (void)hipFreeAsync(part, s);
+    FDR_HIP(e);
+    return FDR_OK;
+}
+
+int fdr_white_balance_u8(int device, const float* const orig_bgr[3], const float* const restored_bgr[3], int rows, int cols,
+                         int stride, unsigned char* out_bgr8, int out_stride_bytes) {
+    if (!orig_bgr || !restored_bgr || !out_bgr8) return fail(FDR_ERR_ARG, "fdr_white_balance_u8: null argument");
+    if (rows <= 0 || cols <= 0 || stride < cols || out_stride_bytes < 3 * cols) return fail(FDR_ERR_ARG, "fdr_white_balance_u8: bad shape");
+    FDR_HIP(hipSetDevice(device));
+    const size_t plane = (size_t)rows * cols * sizeof(float), rowb = (size_t)cols * sizeof(float);
+    float* d = nullptr; unsigned char* d_out = nullptr;
+    FDR_HIP(hipMalloc((void**)&d, 6 * plane));
+    if (hipMalloc((void**)&d_out, (size_t)rows * cols * 3) != hipSuccess) { (void)hipFree(d); return fail(FDR_ERR_ALLOC, "fdr_white_balance_u8: hipMalloc"); }
+    const float* dp[6];
+    hipError_t e = hipSuccess;
+    for (int c = 0; c < 6 && e == hipSuccess; ++c) {
+        const float* src = c < 3 ? orig_bgr[c] : restored_bgr[c - 3];
+        if (!src) { (void)hipFree(d); (void)hipFree(d_out); return fail(FDR_ERR_ARG, "fdr_white_balance_u8: null plane"); }
+        float* dst = d + (size_t)c * rows * cols;
+        dp[c] = dst;
+        e = hipMemcpy2D(dst, rowb, src, (size_t)stride * sizeof(float), rowb, rows, hipMemcpyHostToDevice);
+    }
+    int rc = FDR_OK;
+    if (e == hipSuccess) rc = fdr_white_balance_u8_dev(device, dp, dp + 3, rows, cols, cols, d_out, 3 * cols, nullptr);
+    if (e == hipSuccess && rc == FDR_OK)
+        e = hipMemcpy2D(out_bgr8, (size_t)out_stride_bytes, d_out, (size_t)cols * 3, (size_t)cols * 3, rows, hipMemcpyDeviceToHost);
+    (void)hipFree(d); (void)hipFree(d_out);
+    if (rc != FDR_OK) return rc;
+    FDR_HIP(e);
+    return FDR_OK;
+}
+
 int fdr_synth_image_dev(int device, uint64_t seed, uint64_t first_index, size_t count, float* d_out, void* stream) {
     if (!d_out && count) return fail(FDR_ERR_ARG, "fdr_synth_image_dev: null output");
     FDR_HIP(hipSetDevice(device));

@@ -130,6 +130,17 @@ int cols_minmax_partials(int logm, int N);
 hipError_t launch_normalize(const float* raw, int N, const float2* mm_part, int n_part, const float* mm, float* out,
                             int rows, int cols, int out_stride, hipStream_t s, const NormBatch* batch = nullptr);
 hipError_t launch_psf_motion(int size, double angle_deg, float* d_out, hipStream_t s);
+
+// colour epilogue of the drivers (fdr_color.hip): planar float BGR in [0,1] -> Lab white balance -> interleaved 8-bit BGR
+struct ColorArgs {
+    const float* orig[3];  // blurred input planes B, G, R (the white-balance reference)
+    const float* rest[3];  // restored planes B, G, R
+    int rows, cols, stride;
+    unsigned char* out;    // rows x cols x 3, row stride out_stride bytes
+    int out_stride;
+};
+int color_partials(int rows, int cols);
+hipError_t launch_color_epilogue(const ColorArgs& a, double2* part, hipStream_t s);
 hipError_t launch_synth(uint64_t seed, uint64_t first, size_t count, float* d_out, hipStream_t s);
 hipError_t launch_dft_naive(const float2* src, float2* dst, int n, int inverse, hipStream_t s);
 

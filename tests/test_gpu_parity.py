@@ -293,6 +293,42 @@ def test_host_batch_pipeline_equals_one_by_one(fdr, oracle, mode_name, pinned):
     _assert_same(np.array(got), one, "host batch pipeline vs one by one")
 
 
+def test_white_balance_epilogue_on_device(fdr):
+    """fdr_white_balance_u8 (serial.cpp:43-54 / utils.hpp:55-71 on the device) against a float64 numpy model of
+    the same formulae; OpenCV's Lab arithmetic is third party and unpinned: +-1 at 8 bit."""
+    rng = np.random.default_rng(7)
+    rows, cols = 97, 203
+    orig = [rng.random((rows, cols), dtype=np.float32) for _ in range(3)]
+    rest = [np.clip(o * 0.8 + 0.15 * rng.random((rows, cols), dtype=np.float32), 0, 1).astype(np.float32) for o in orig]
+    got = fdr.applyWhiteBalance_u8(orig, rest)
+
+    def to_lab(b, g, r):
+        lin = lambda c: np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+        b, g, r = (lin(np.clip(c.astype(np.float64), 0, 1)) for c in (b, g, r))
+        X = (0.412453 * r + 0.357580 * g + 0.180423 * b) / 0.950456
+        Y = 0.212671 * r + 0.715160 * g + 0.072169 * b
+        Z = (0.019334 * r + 0.119193 * g + 0.950227 * b) / 1.088754
+        f = lambda t: np.where(t > 0.008856, np.cbrt(t), 7.787 * t + 16.0 / 116.0)
+        L = np.where(Y > 0.008856, 116.0 * f(Y) - 16.0, 903.3 * Y)
+        return L, 500.0 * (f(X) - f(Y)), 200.0 * (f(Y) - f(Z))
+
+    Lo, _, _ = to_lab(*orig)
+    L, a, bb = to_lab(*rest)
+    L = np.clip(L * (Lo.mean() / (L.mean() + 1e-6)), 0, 100)
+    fy = (L + 16.0) / 116.0
+    fx, fz = fy + a / 500.0, fy - bb / 200.0
+    finv = lambda t: np.where(t > 0.206893, t ** 3, (t - 16.0 / 116.0) / 7.787)
+    Y = np.where(L > 7.9996, fy ** 3, L / 903.3)
+    X, Z = finv(fx) * 0.950456, finv(fz) * 1.088754
+    r = 3.240479 * X - 1.537150 * Y - 0.498535 * Z
+    g = -0.969256 * X + 1.875991 * Y + 0.041556 * Z
+    b = 0.055648 * X - 0.204043 * Y + 1.057311 * Z
+    comp = lambda c: np.where(c <= 0.0031308, 12.92 * c, 1.055 * np.clip(c, 1e-30, None) ** (1 / 2.4) - 0.055)
+    want = np.stack([np.clip(np.rint(comp(np.clip(c, 0, 1)) * 255.0), 0, 255) for c in (b, g, r)], axis=-1)
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert got.shape == (rows, cols, 3) and d.max() <= 1 and np.count_nonzero(d) < 0.02 * d.size, (int(d.max()), int(np.count_nonzero(d)))
+
+
 def test_synth_generator_matches_oracle_bits(fdr, oracle):
     import torch
     d = torch.empty(5000, dtype=torch.float32, device="cuda")
@@ -375,6 +411,14 @@ def test_drop_in_cli(fdr, tmp_path):
         _assert_same(planes[k], want, "CLI plane %d" % k)
     res = np.asarray(Image.open(out_png))
     assert res.shape == (h, w, 3) and res.dtype == np.uint8 and 20 < res.mean() < 235
+    # the colour epilogue (Lab white balance, 8 bit) ran on the device; the host restatement of the same OpenCV
+    # formulae (--host-epilogue) must agree within 1 at 8 bit (powf / cbrtf differ in the last place)
+    out_host = str(tmp_path / "car_host.png")
+    r2 = subprocess.run([_os.path.join(root, "tools", "cli", "gpu"), png, "40", "45", "--mode", "parity", "--out", out_host,
+                         "--host-epilogue"], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    d = np.abs(res.astype(np.int16) - np.asarray(Image.open(out_host)).astype(np.int16))
+    assert d.max() <= 1 and np.count_nonzero(d) < 0.02 * d.size, (int(d.max()), int(np.count_nonzero(d)))
     # usage / unreadable image behave as the reference driver (return -1 -> exit status 255)
     assert subprocess.run([_os.path.join(root, "tools", "cli", "gpu")], capture_output=True).returncode == 255
     bad = subprocess.run([_os.path.join(root, "tools", "cli", "gpu"), "/nonexistent.png", "40", "45"], capture_output=True, text=True)

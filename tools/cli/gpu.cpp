@@ -1,4 +1,4 @@
-// gpu.cpp -- ./gpu <img-path> <psf-length> <psf-angle> [--out file] [--mode fast|parity] [--norm padded|cropped]
+// gpu.cpp -- ./gpu <img-path> <psf-length> <psf-angle> [--out file] [--mode fast|parity] [--norm padded|cropped] [--host-epilogue]
 // Drop-in counterpart of the reference's gpu.cpp (argument meaning, printed lines and exit codes as at
 // gpu.cpp:57-138 of the reference): read image, /255, PSF, K = 0.01, split BGR, warm-up call, timed
 // wienerDeblur_RGB_optimized, timed wienerDeblur_RGB_naive, merge, Lab white balance, 8-bit result.
@@ -21,10 +21,12 @@ int main(int argc, char** argv) {
     int psf_length = atoi(argv[2]);
     double psf_angle = atof(argv[3]);
     string out_path, raw_path;
+    bool host_epilogue = false;  // Lab white balance on the host (the A/B reference of the device epilogue)
     for (int i = 4; i < argc; ++i) {
         string a = argv[i];
         if (a == "--out" && i + 1 < argc) out_path = argv[++i];
         else if (a == "--raw-out" && i + 1 < argc) raw_path = argv[++i];  // restored float planes B,G,R before white balance
+        else if (a == "--host-epilogue") host_epilogue = true;
         else if (a == "--mode" && i + 1 < argc) fft_gpu::set_mode(string(argv[++i]) == "parity" ? FDR_MODE_PARITY : FDR_MODE_FAST);
         else if (a == "--norm" && i + 1 < argc) fft_gpu::set_norm_area(string(argv[++i]) == "cropped" ? FDR_NORM_CROPPED : FDR_NORM_PADDED);
         else { cout << "Usage: ./gpu <img-path> <psf-length> <psf-angle>\n"; return -1; }
@@ -67,12 +69,28 @@ int main(int argc, char** argv) {
         fclose(f);
     }
 
-    Mat merged_float;
-    merge(channels, merged_float);
-    Mat merged_Lab = fdr_io::bgr2lab(merged_float), img_orig_Lab = fdr_io::bgr2lab(img);
-    Mat corrected_Lab = applyWhiteBalance(merged_Lab, img_orig_Lab);
-    Mat corrected_BGR = fdr_io::lab2bgr(corrected_Lab);
-    corrected_BGR.convertTo(corrected_BGR, CV_8U, 255.0);
+    Mat corrected_BGR;
+    if (host_epilogue) {  // the reference's sequence on the host (gpu.cpp:123-137)
+        Mat merged_float;
+        merge(channels, merged_float);
+        Mat merged_Lab = fdr_io::bgr2lab(merged_float), img_orig_Lab = fdr_io::bgr2lab(img);
+        Mat corrected_Lab = applyWhiteBalance(merged_Lab, img_orig_Lab);
+        corrected_BGR = fdr_io::lab2bgr(corrected_Lab);
+        corrected_BGR.convertTo(corrected_BGR, CV_8U, 255.0);
+    } else {              // the same epilogue in two device passes (fdr_white_balance_u8)
+        const float* orig[3]; const float* rest[3];
+        vector<Mat> keep_o, keep_r;
+        for (int c = 0; c < 3; ++c) {
+            keep_o.push_back(input[c].isContinuous() ? input[c] : input[c].clone());
+            keep_r.push_back(channels[c].isContinuous() ? channels[c] : channels[c].clone());
+        }
+        for (int c = 0; c < 3; ++c) { orig[c] = keep_o[c].ptr<float>(0); rest[c] = keep_r[c].ptr<float>(0); }
+        corrected_BGR = Mat(img.rows, img.cols, CV_8UC3);
+        if (fdr_white_balance_u8(0, orig, rest, img.rows, img.cols, img.cols, corrected_BGR.ptr<unsigned char>(0), 3 * img.cols) != FDR_OK) {
+            cerr << "Error: " << __FILE__ << ":" << __LINE__ << ", " << fdr_last_error() << "\n";
+            exit(1);
+        }
+    }
     if (!out_path.empty()) {
         if (!fdr_io::imwrite(out_path, corrected_BGR)) { cout << "Cannot write " << out_path << "\n"; return -1; }
         cout << "Wrote " << out_path << "\n";
