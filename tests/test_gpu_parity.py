@@ -95,7 +95,7 @@ def _image(oracle, rows, cols, seed):
     return oracle.synth_image(seed, 0, rows * cols).reshape(rows, cols)
 
 
-@pytest.mark.parametrize("shape", [(64, 64), (256, 256), (100, 200), (782 // 4, 1920 // 4), (1024, 1024)])
+@pytest.mark.parametrize("shape", [(64, 64), (256, 256), (100, 200), (782 // 4, 1920 // 4), (1024, 1024), (782, 1920)])
 def test_wiener_parity_bit_exact(fdr, oracle, shape):
     psf = oracle.motion_blur_kernel(50 if min(shape) >= 64 else 15, 30.0)
     img = _image(oracle, shape[0], shape[1], 0x5EED0002)
@@ -105,7 +105,7 @@ def test_wiener_parity_bit_exact(fdr, oracle, shape):
     assert got.min() >= 0.0 and got.max() <= 1.0
 
 
-@pytest.mark.parametrize("shape", [(64, 64), (256, 256), (100, 200), (1024, 1024), (330, 640)])
+@pytest.mark.parametrize("shape", [(64, 64), (256, 256), (100, 200), (1024, 1024), (330, 640), (782, 1920)])
 def test_wiener_fast_within_tolerance(fdr, oracle, shape):
     psf = oracle.motion_blur_kernel(50 if min(shape) >= 64 else 15, 30.0)
     img = _image(oracle, shape[0], shape[1], 0x5EED0002)
@@ -417,6 +417,10 @@ def test_drop_in_cli(fdr, tmp_path):
     r2 = subprocess.run([_os.path.join(root, "tools", "cli", "gpu"), png, "40", "45", "--mode", "parity", "--out", out_host,
                          "--host-epilogue"], capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0, r2.stdout + r2.stderr
+    # the reference's (commented-out) areChannelsEqual check, fast mode against the serial-equivalent parity mode
+    r3 = subprocess.run([_os.path.join(root, "tools", "cli", "gpu"), png, "40", "45", "--mode", "fast", "--verify"],
+                        capture_output=True, text=True, timeout=300)
+    assert r3.returncode == 0 and "[Success] The results from serial and GPU implementations are identical." in r3.stdout, r3.stdout + r3.stderr
     d = np.abs(res.astype(np.int16) - np.asarray(Image.open(out_host)).astype(np.int16))
     assert d.max() <= 1 and np.count_nonzero(d) < 0.02 * d.size, (int(d.max()), int(np.count_nonzero(d)))
     # usage / unreadable image behave as the reference driver (return -1 -> exit status 255)

@@ -8,9 +8,45 @@
 #include "utils.hpp"
 #include "fft/fft.hpp"
 #include "fdr_image_io.hpp"
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <iostream>
 #include <string>
+
+// gpu.cpp:13-55 of the reference: L-inf <= epsilon per channel, else PSNR >= 30 dB still passes ("floating point
+// drift").  The reference compares serial vs GPU with it (call commented out at gpu.cpp:116-121); here the serial
+// side is the parity mode of this library, whose result is bit-identical to the serial path (tests/), so the check
+// runs entirely on the GPU: epsilon 1e-4, the tolerance BASELINE states.
+static bool areChannelsEqual(const vector<Mat>& vec1, const vector<Mat>& vec2, double epsilon = 1e-4) {
+    if (vec1.size() != vec2.size()) { cerr << "Error: Channel count mismatch.\n"; return false; }
+    for (size_t i = 0; i < vec1.size(); ++i) {
+        const Mat &m1 = vec1[i], &m2 = vec2[i];
+        if (m1.rows != m2.rows || m1.cols != m2.cols || m1.type() != m2.type()) { cerr << "Error: Size/Type mismatch.\n"; return false; }
+        double diff = 0.0, sq = 0.0;
+        for (int r = 0; r < m1.rows; ++r)
+            for (int c = 0; c < m1.cols; ++c) {
+                const double d = (double)m1.ptr<float>(r)[c] - (double)m2.ptr<float>(r)[c];
+                diff = std::max(diff, std::fabs(d));
+                sq += d * d;
+            }
+        const double mse = sq / ((double)m1.rows * m1.cols);
+        const double psnr = mse > 1e-10 ? 10.0 * log10(1.0 / mse) : 100.0;
+        if (diff > epsilon) {
+            if (psnr >= 30.0) {
+                cout << "[Info] Channel " << i << " has floating point drift."
+                     << "\n       Max Diff: " << diff << "\n       PSNR: " << psnr << " dB (Excellent! > 30dB is good)"
+                     << "\n       -> Verification PASSED (Relaxed)." << endl;
+            } else {
+                cerr << "[Error] Content mismatch in channel " << i << ".\n";
+                cerr << "       Max pixel difference: " << diff << " (Threshold: " << epsilon << ")\n";
+                cerr << "       PSNR: " << psnr << " dB (Too low!)\n";
+                return false;
+            }
+        }
+    }
+    return true;
+}
 
 int main(int argc, char** argv) {
     if (argc < 4) {
@@ -21,12 +57,14 @@ int main(int argc, char** argv) {
     int psf_length = atoi(argv[2]);
     double psf_angle = atof(argv[3]);
     string out_path, raw_path;
+    bool verify = false;         // --verify: areChannelsEqual(parity-mode result, this run's result)
     bool host_epilogue = false;  // Lab white balance on the host (the A/B reference of the device epilogue)
     for (int i = 4; i < argc; ++i) {
         string a = argv[i];
         if (a == "--out" && i + 1 < argc) out_path = argv[++i];
         else if (a == "--raw-out" && i + 1 < argc) raw_path = argv[++i];  // restored float planes B,G,R before white balance
         else if (a == "--host-epilogue") host_epilogue = true;
+        else if (a == "--verify") verify = true;
         else if (a == "--mode" && i + 1 < argc) fft_gpu::set_mode(string(argv[++i]) == "parity" ? FDR_MODE_PARITY : FDR_MODE_FAST);
         else if (a == "--norm" && i + 1 < argc) fft_gpu::set_norm_area(string(argv[++i]) == "cropped" ? FDR_NORM_CROPPED : FDR_NORM_PADDED);
         else { cout << "Usage: ./gpu <img-path> <psf-length> <psf-angle>\n"; return -1; }
@@ -60,6 +98,16 @@ int main(int argc, char** argv) {
     const double naive_time = getElapsedMs(t_start, t_end);
     cout << "Deblurring 3 channels took(gpu): " << naive_time << " ms\n";
     printf("[Speedup] %.2fx ms\n", naive_time / opt_time);
+
+    if (verify) {  // the check of gpu.cpp:116-121, serial side = parity mode (bit-identical to ./serial)
+        const int mode = fft_gpu::mode_ref();
+        vector<Mat> serial_channels = input;
+        fft_gpu::set_mode(FDR_MODE_PARITY);
+        fft_gpu::wienerDeblur_RGB_optimized(serial_channels, psf, K);
+        fft_gpu::set_mode(mode);
+        if (areChannelsEqual(serial_channels, channels)) cout << "[Success] The results from serial and GPU implementations are identical.\n";
+        else cout << "[Error] The results from serial and GPU implementations differ.\n";
+    }
 
     if (!raw_path.empty()) {
         FILE* f = fopen(raw_path.c_str(), "wb");
