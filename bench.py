@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--size", type=int, default=4096, help="synthetic image edge (power of two)")
     ap.add_argument("--batch", type=int, default=24, help="images per GPU per step")
     ap.add_argument("--mode", choices=["fast", "parity"], default="fast")
-    ap.add_argument("--streams", type=int, default=3, help="internal streams / workspaces the batch alternates over")
+    ap.add_argument("--streams", type=int, default=0, help="internal streams / workspaces the batch alternates over (0 = 3, or 2 up to 2048^2)")
     ap.add_argument("--group", type=int, default=0, help="images per pass-B' launch (fast mode; 1..4, streams*group <= 8; 0 = 4 up to 2048^2, else 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=0, help="edge of the CPU-baseline sample (default: --size, capped at 4096)")
@@ -127,8 +127,11 @@ def main():
     spectrum = "half" if (args.mode == "fast" and not (flags & fdr.FLAG_FULL_SPECTRUM) and S >= 32) else "full"
     plan = fdr.Plan(S, S, mode, device=local_rank, flags=flags)
     stream = torch.cuda.current_stream().cuda_stream
+    # measured best: 4096^2 and up 3 streams x 1 image per launch; small images 2 streams x 4 images per launch
+    if args.streams <= 0:
+        args.streams = 2 if (S <= 2048 and args.mode == "fast") else 3
     if args.group <= 0:
-        args.group = 4 if S <= 2048 else 1  # small images: several per column launch fill the chip (measured)
+        args.group = max(1, min(4, 8 // args.streams)) if S <= 2048 else 1
     plan.set_batching(args.streams, args.group if args.mode == "fast" else 1)
     plan.set_psf_motion(50, 30.0, 0.01, stream=stream)  # PSF generated, padded and transformed on the device
     imgs = torch.empty((B, S, S), dtype=torch.float32, device=dev)
