@@ -155,6 +155,15 @@ def test_errors(fdr):
         p.set_psf(np.ones((3, 3), np.float32) / 9)
         with pytest.raises(fdr.FdrError):
             p.wiener(np.zeros((65, 64), np.float32))  # image larger than the plan
+        with pytest.raises(fdr.FdrError):
+            p.wiener_batch(np.zeros((2, 65, 64), np.float32))  # host batch: the same shape check
+        assert p.wiener_batch(np.zeros((0, 64, 64), np.float32)).shape == (0, 64, 64)  # empty batch is a no-op
+        for bad in ((0, 1), (1, 0), (1, 5), (3, 3), (9, 1)):  # streams * group <= 8, group <= 4
+            with pytest.raises(fdr.FdrError):
+                p.set_batching(*bad)
+        p.set_batching(2, 4)
+    with pytest.raises(fdr.FdrError):  # colour epilogue: three planes of one shape, non-empty
+        fdr.applyWhiteBalance_u8([np.zeros((0, 4), np.float32)] * 3, [np.zeros((0, 4), np.float32)] * 3)
 
 
 # ------------------------------------------------------------------------------------------------
