@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=0, help="internal streams / workspaces the batch alternates over (0 = 3, or 2 up to 2048^2)")
     ap.add_argument("--group", type=int, default=0, help="images per pass-B' launch (fast mode; 1..4, streams*group <= 8; 0 = 4 up to 2048^2, else 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals on a one-GPU box)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-size", type=int, default=0, help="edge of the CPU-baseline sample (default: --size, capped at 4096)")
     return ap.parse_args()
 
@@ -102,12 +104,12 @@ def main():
     from importlib import import_module
     batch_mod = import_module(PKG + ".batch")
 
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    comm = batch_mod.Comm(backend="nccl", device=dev)
+    comm = batch_mod.Comm(backend=args.backend, device=dev)
     rank, world = comm.rank, comm.world
 
     S, B = args.size, args.batch
