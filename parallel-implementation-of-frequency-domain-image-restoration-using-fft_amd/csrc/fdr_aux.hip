@@ -279,11 +279,14 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict_
         const int x = (int)(sgi % segs_per_row) * W + threadIdx.x * (VEC4 ? 4 : 1);
         if (VEC4) {
             if (x < cols) {  // cols % 4 == 0
-                const float4 v = *reinterpret_cast<const float4*>(raw + (size_t)y * N + x);
+                typedef float nf4 __attribute__((ext_vector_type(4)));
+                const nf4 vv = __builtin_nontemporal_load(reinterpret_cast<const nf4*>(raw + (size_t)y * N + x));  // last use
+                const float4 v = make_float4(vv.x, vv.y, vv.z, vv.w);
                 float4 o;
                 o.x = v.x * fscale; o.y = v.y * fscale; o.z = v.z * fscale; o.w = v.w * fscale;
                 o.x = o.x + fshift; o.y = o.y + fshift; o.z = o.z + fshift; o.w = o.w + fshift;
-                *reinterpret_cast<float4*>(out + (size_t)y * out_stride + x) = o;
+                nf4 oo; oo.x = o.x; oo.y = o.y; oo.z = o.z; oo.w = o.w;
+                __builtin_nontemporal_store(oo, reinterpret_cast<nf4*>(out + (size_t)y * out_stride + x));  // written once, read by the caller
             }
         } else {
             if (x < cols) {

@@ -177,8 +177,9 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
             for (int q = 0; q < Core::RHO0; ++q) {
                 const int s = u * Core::RHO0 + q;
                 const unsigned n = (unsigned)Core::in_index(tid, u, q);
-                z[0][s] = make_float2(row0[n], row1[n]);
-                z[1][s] = make_float2(row2[n], row3[n]);
+                // the image is read exactly once: keep it out of the caches that hold the intermediates
+                z[0][s] = make_float2(__builtin_nontemporal_load(row0 + n), __builtin_nontemporal_load(row1 + n));
+                z[1][s] = make_float2(__builtin_nontemporal_load(row2 + n), __builtin_nontemporal_load(row3 + n));
             }
     } else {
 #pragma unroll
