@@ -1237,16 +1237,18 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PE
 template <int LOGM>
 struct Panel16Geom {
     static constexpr int T = Steps<LOGM, 4>::T;
-    static constexpr int G = T >= 256 ? 1 : 256 / T;  // panels per workgroup
+    // one panel per workgroup at every size: with short columns (64 or 128 threads per transform) grouping several
+    // panels into a 256-thread workgroup was measured slower (2048^2 x 4 images: 45.1 vs 39.7 us) and leaves CUs idle
+    static constexpr int G = 1;
     static constexpr int THREADS = T * G;
 };
 
-template <int LOGM, int G = Panel16Geom<LOGM>::G>
-__global__ __launch_bounds__((Steps<LOGM, 4>::T * G), 2) void fft_cols_panel_fused16_kernel(
+template <int LOGM>
+__global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_fused16_kernel(
     const PanelBatch pb, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const unsigned pstride,
     const int npanels, const int ntiles, const int packed0) {
     using St = Steps<LOGM, 4>;
-    constexpr int T = St::T, M = St::L, V = 16;
+    constexpr int G = Panel16Geom<LOGM>::G, T = St::T, M = St::L, V = 16;
     using Core = FftCore<LOGM, 4, 2, PolicyFast, 4>;
     __shared__ float2 lds[G * 2 * St::BUF];
     const int g = G == 1 ? 0 : (int)(threadIdx.x >> St::LOGT);
@@ -1385,13 +1387,6 @@ static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const floa
             if (a.v16) {  // 16 values per thread, two 256-thread workgroups per CU
                 using G16 = Panel16Geom<LOGM>;
                 const int nt16 = (npanels + G16::G - 1) / G16::G;
-                // short columns: several panels share a workgroup to reach 256 threads -- unless that leaves CUs idle
-                // (1024-point columns: 32 workgroups per image); then one panel per workgroup spreads the launch
-                if (G16::G > 1 && nt16 * pb.nimg < 2 * (a.num_cu > 0 ? a.num_cu : 256)) {
-                    hipLaunchKernelGGL((fft_cols_panel_fused16_kernel<LOGM, 1>), dim3(npanels, pb.nimg), dim3(Steps<LOGM, 4>::T), 0, s, pb,
-                                       a.filt, tw, (unsigned)ps, npanels, npanels, a.packed0);
-                    return hipGetLastError();
-                }
                 hipLaunchKernelGGL((fft_cols_panel_fused16_kernel<LOGM>), dim3(nt16, pb.nimg), dim3(G16::THREADS), 0, s, pb, a.filt,
                                    tw, (unsigned)ps, npanels, nt16, a.packed0);
                 return hipGetLastError();
