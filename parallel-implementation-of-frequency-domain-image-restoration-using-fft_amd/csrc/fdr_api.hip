@@ -835,12 +835,19 @@ int fdr_fft2d_c2c_dev(fdr_plan* p, float* d_data, int inverse, void* stream) {
 int fdr_fft2d_c2c(fdr_plan* p, float* data_host, int inverse) {
     if (!p || !data_host) return fail(FDR_ERR_ARG, "fdr_fft2d_c2c: null argument");
     FDR_HIP(hipSetDevice(p->device));
-    const size_t bytes = (size_t)p->M * p->N * sizeof(float2);
-    // p->work is free between operator calls; use it as the staging buffer
-    FDR_HIP(hipMemcpy(p->work, data_host, bytes, hipMemcpyHostToDevice));
-    int rc = dft2d_dev(p, p->work, p->work2, inverse != 0, nullptr);
+    const size_t elems = (size_t)p->M * p->N, bytes = elems * sizeof(float2);
+    // p->work is free between operator calls and serves as the staging buffer -- unless the plan keeps only the
+    // half spectrum there (fast panel mode: about M*N/2 elements), where a full-size buffer is allocated for the call
+    float2* buf = p->work;
+    const bool own = p->ws_elems < elems;
+    if (own) FDR_HIP(hipMalloc((void**)&buf, bytes));
+    hipError_t e = hipMemcpy(buf, data_host, bytes, hipMemcpyHostToDevice);
+    int rc = FDR_OK;
+    if (e == hipSuccess) rc = dft2d_dev(p, buf, p->work2, inverse != 0, nullptr);
+    if (e == hipSuccess && rc == FDR_OK) e = hipMemcpy(data_host, buf, bytes, hipMemcpyDeviceToHost);
+    if (own) (void)hipFree(buf);
     if (rc != FDR_OK) return rc;
-    FDR_HIP(hipMemcpy(data_host, p->work, bytes, hipMemcpyDeviceToHost));
+    FDR_HIP(e);
     return FDR_OK;
 }
 

@@ -66,6 +66,20 @@ def test_fft2d_parity_bit_exact(fdr, oracle, shape, inverse):
     _assert_same(got, oracle.dft2d(x, inverse), "fft2d %s" % (shape,))
 
 
+@pytest.mark.parametrize("shape", [(8, 8), (64, 32), (256, 1024), (2048, 512)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_fft2d_fast_close_to_float64(fdr, shape, inverse):
+    """fft_gpu::my_dft2D in the fast mode (double-generated twiddles, FMA butterflies): unscaled, against numpy's
+    float64 transform; rel-L2 well below the serial path's own error (1e-6 .. 1e-5)."""
+    rng = np.random.default_rng(shape[0] * 31 + shape[1])
+    x = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+    with fdr.Plan(shape[0], shape[1], fdr.MODE_FAST) as p:
+        got = p.fft2d(x, inverse)
+    want = np.fft.ifft2(x.astype(np.complex128)) * (shape[0] * shape[1]) if inverse else np.fft.fft2(x.astype(np.complex128))
+    rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert rel < 2e-6, rel
+
+
 @pytest.mark.parametrize("shape", [(1, 1), (1, 8), (2, 2), (4, 16), (16, 4), (2, 1024)])
 def test_fft2d_small_dims_simple_path(fdr, oracle, shape):
     rng = np.random.default_rng(11)
