@@ -452,6 +452,35 @@ def test_drop_in_cli(fdr, tmp_path):
     assert bad.returncode == 255 and "Cannot read image" in bad.stdout
 
 
+def test_cpp_shim_surface(fdr, oracle, tmp_path):
+    """tools/cli/shim_test.cpp calls every name of the drop-in C++ surface (namespace fft_gpu of fft/fft.hpp:31-45 and
+    the utils.hpp helpers) the way a caller of the reference would; its dumps must equal what the Python binding of
+    the same library (and, in parity mode, the CPU oracle) gives for the same inputs."""
+    import subprocess
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", _os.path.join(root, "tools", "cli"), "-s", "shim_test"])
+    r = subprocess.run([_os.path.join(root, "tools", "cli", "shim_test"), str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "shim ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+    rd = lambda name, *shape: np.fromfile(str(tmp_path / name), dtype=np.float32).reshape(shape)
+    cplx = lambda a: a[..., 0::2] + 1j * a[..., 1::2]
+    psf, img = rd("psf.f32", 15, 15), rd("img.f32", 100, 200)
+    _assert_same(psf, oracle.motion_blur_kernel(15, 30.0), "motionBlurKernel")
+    _assert_same(rd("wiener_parity.f32", 100, 200), oracle.serial_channel(img, psf, 0.01), "wienerDeblur_myfft (parity) vs oracle")
+    _assert_same(rd("wiener_fast.f32", 100, 200), fdr.wienerDeblur_myfft(img, psf, 0.01, mode=fdr.MODE_FAST), "wienerDeblur_myfft (fast)")
+    _assert_same(rd("rgb1.f32", 100, 200), fdr.wienerDeblur_myfft(img * np.float32(0.75), psf, 0.01, mode=fdr.MODE_FAST), "wienerDeblur_RGB_* channel 1")
+    x = cplx(rd("fft1d_in.f32", 128)).astype(np.complex64)
+    _assert_same(cplx(rd("fft1d_fwd.f32", 128)).astype(np.complex64), oracle.fft_radix2(x, False), "fft_radix2_kernel")
+    _assert_same(cplx(rd("fft1d_inv.f32", 128)).astype(np.complex64), oracle.fft_radix2(x, True), "transform_row_kernel (inverse)")
+    z = cplx(rd("dft_in.f32", 24)).astype(np.complex64)
+    got = cplx(rd("dft_fwd.f32", 24))
+    assert np.abs(got - np.fft.fft(z.astype(np.complex128))).max() < 1e-5, "dft_naive_kernel"
+    c2 = cplx(rd("fft2d_in.f32", 32, 128)).astype(np.complex64)
+    _assert_same(cplx(rd("fft2d_fwd.f32", 32, 128)).astype(np.complex64), oracle.dft2d(c2, False), "my_dft2D_forward")
+    _assert_same(cplx(rd("fft2d_inv.f32", 32, 128)).astype(np.complex64), oracle.dft2d(c2, True), "my_dft2D(inverse)")
+    rt = cplx(rd("fft2d_rt.f32", 32, 128)) / (32 * 64)
+    assert np.abs(rt - c2).max() < 1e-5, "my_dft2D round trip"
+
+
 @pytest.mark.parametrize("shape", [(8, 8), (16, 32), (32, 16), (8, 64), (64, 8), (32, 32), (5, 7), (33, 17), (1, 100), (100, 1)])
 @pytest.mark.parametrize("mode_name", ["MODE_PARITY", "MODE_FAST"])
 def test_small_and_ragged_shapes(fdr, oracle, shape, mode_name):

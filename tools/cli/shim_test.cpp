@@ -1,0 +1,87 @@
+// shim_test.cpp -- exercises every name of the drop-in C++ surface (include/fft/fft.hpp: namespace fft_gpu as declared at
+// fft/fft.hpp:31-45 of the reference; include/utils.hpp: utils.hpp:9-71) the way a caller of the reference would, and
+// dumps the results as raw float32 for tests/test_gpu_parity.py::test_cpp_shim_surface to compare with the Python
+// binding of the same library.  usage: shim_test <out-dir>
+#include "utils.hpp"
+#include "fft/fft.hpp"
+#include <cstdio>
+#include <string>
+
+static void dump(const std::string& path, const float* p, size_t n) {
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f || std::fwrite(p, sizeof(float), n, f) != n) { std::fprintf(stderr, "cannot write %s\n", path.c_str()); std::exit(2); }
+    std::fclose(f);
+}
+static void dump(const std::string& path, const Mat& m) {
+    std::vector<float> v;
+    const int cn = m.channels();
+    for (int r = 0; r < m.rows; ++r) v.insert(v.end(), m.ptr<float>(r), m.ptr<float>(r) + (size_t)m.cols * cn);
+    dump(path, v.data(), v.size());
+}
+static float lcg(unsigned& s) { s = s * 1664525u + 1013904223u; return (float)(s >> 8) * (1.0f / 16777216.0f); }
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::printf("usage: shim_test <out-dir>\n"); return -1; }
+    const std::string out = std::string(argv[1]) + "/";
+    unsigned seed = 12345u;
+
+    // utils.hpp: nextPowerOfTwo / getNextPowerOf2 / isPowerOfTwo / autoPadToPowerOfTwo / motionBlurKernel / getElapsedMs
+    if (nextPowerOfTwo(782) != 1024 || getNextPowerOf2(1920) != 2048 || !isPowerOfTwo(4096) || isPowerOfTwo(782)) return 3;
+    auto t0 = high_resolution_clock::now();
+    Mat psf = motionBlurKernel(15, 30.0);
+    if (getElapsedMs(t0, high_resolution_clock::now()) < 0.0) return 4;
+    dump(out + "psf.f32", psf);
+    Mat img(100, 200, CV_32F);
+    for (int r = 0; r < img.rows; ++r) for (int c = 0; c < img.cols; ++c) img.ptr<float>(r)[c] = lcg(seed);
+    dump(out + "img.f32", img);
+    Mat padded = autoPadToPowerOfTwo(img);
+    if (padded.rows != 128 || padded.cols != 256 || padded.ptr<float>(127)[255] != 0.0f || padded.ptr<float>(99)[199] != img.ptr<float>(99)[199]) return 5;
+
+    // fft_gpu::wienerDeblur_myfft (fft/fft.hpp:44) in both arithmetic modes
+    fft_gpu::set_mode(FDR_MODE_PARITY);
+    dump(out + "wiener_parity.f32", fft_gpu::wienerDeblur_myfft(img, psf, 0.01f));
+    fft_gpu::set_mode(FDR_MODE_FAST);
+    dump(out + "wiener_fast.f32", fft_gpu::wienerDeblur_myfft(img, psf, 0.01f));
+
+    // fft_gpu::wienerDeblur_RGB_optimized / _naive (fft/fft.hpp:32-33): three channels replaced in place
+    std::vector<Mat> ch;
+    for (int k = 0; k < 3; ++k) { Mat c = img.clone(); for (int r = 0; r < c.rows; ++r) for (int x = 0; x < c.cols; ++x) c.ptr<float>(r)[x] *= 0.5f + 0.25f * k; ch.push_back(c); }
+    std::vector<Mat> a = ch, b = ch;
+    fft_gpu::wienerDeblur_RGB_optimized(a, psf, 0.01f);
+    fft_gpu::wienerDeblur_RGB_naive(b, psf, 0.01f);
+    for (int k = 0; k < 3; ++k) {
+        if (a[k].rows != 100 || a[k].cols != 200) return 6;
+        for (int r = 0; r < 100; ++r) for (int x = 0; x < 200; ++x) if (a[k].ptr<float>(r)[x] != b[k].ptr<float>(r)[x]) return 7;
+    }
+    dump(out + "rgb1.f32", a[1]);
+
+    // fft_gpu::fft_radix2_kernel / transform_row_kernel / dft_naive_kernel (fft/fft.hpp:35-39): interleaved complex by pointer
+    std::vector<float> x(2 * 64), y, z(2 * 12);
+    for (auto& v : x) v = lcg(seed) - 0.5f;
+    for (auto& v : z) v = lcg(seed) - 0.5f;
+    dump(out + "fft1d_in.f32", x.data(), x.size());
+    dump(out + "dft_in.f32", z.data(), z.size());
+    y = x;
+    fft_gpu::fft_radix2_kernel(y.data(), 64, false);
+    dump(out + "fft1d_fwd.f32", y.data(), y.size());
+    y = x;
+    fft_gpu::transform_row_kernel(y.data(), 64, true);
+    dump(out + "fft1d_inv.f32", y.data(), y.size());
+    fft_gpu::dft_naive_kernel(z.data(), 12, false);
+    dump(out + "dft_fwd.f32", z.data(), z.size());
+
+    // fft_gpu::my_dft2D / my_dft2D_forward / my_dft2D_inverse (fft/fft.hpp:40-42) on a CV_32FC2 Mat
+    Mat c2(32, 64, CV_32FC2);
+    for (int r = 0; r < 32; ++r) for (int i = 0; i < 128; ++i) c2.ptr<float>(r)[i] = lcg(seed) - 0.5f;
+    dump(out + "fft2d_in.f32", c2);
+    Mat f2 = c2.clone();
+    fft_gpu::my_dft2D_forward(f2);
+    dump(out + "fft2d_fwd.f32", f2);
+    fft_gpu::my_dft2D_inverse(f2);  // unscaled round trip: 32*64 times the input
+    dump(out + "fft2d_rt.f32", f2);
+    Mat g2 = c2.clone();
+    fft_gpu::my_dft2D(g2, true);
+    dump(out + "fft2d_inv.f32", g2);
+    std::printf("shim ok\n");
+    return 0;
+}
