@@ -118,6 +118,8 @@ struct fdr_plan {
     float2* filt = nullptr;   // H (parity) or W (fast)
     float* raw = nullptr;     // M x N real plane before normalisation
     float* psf_dev = nullptr; // staging for host-pointer / generated PSFs
+    float *stage_in = nullptr, *stage_out = nullptr;  // device staging of the host-pointer entry (kept between calls)
+    size_t stage_cap = 0;
     size_t psf_cap = 0;
     float* mm = nullptr;       // final {min, max}
     float2* mm_part = nullptr; // per-workgroup partials
@@ -575,6 +577,7 @@ int fdr_plan_destroy(fdr_plan* p) {
     (void)hipFree(p->tw_row_f); (void)hipFree(p->tw_row_i); (void)hipFree(p->tw_col_f); (void)hipFree(p->tw_col_i);
     (void)hipFree(p->work); (void)hipFree(p->work2); (void)hipFree(p->filt); (void)hipFree(p->raw);
     (void)hipFree(p->psf_dev); (void)hipFree(p->mm); (void)hipFree(p->mm_part);
+    (void)hipFree(p->stage_in); (void)hipFree(p->stage_out);
     delete p;
     return FDR_OK;
 }
@@ -730,10 +733,21 @@ int fdr_wiener_f32(fdr_plan* p, const float* img_host, int rows, int cols, int s
     if (rows <= 0 || cols <= 0 || rows > p->M || cols > p->N || stride < cols || out_stride < cols)
         return fail(FDR_ERR_ARG, "fdr_wiener_f32: image shape does not fit the plan");
     FDR_HIP(hipSetDevice(p->device));
-    float *d_in = nullptr, *d_out = nullptr;
+    // device staging of the image and of the result: owned by the plan and kept between calls (the per-channel loop
+    // of the drivers calls this three times; the reference's _optimized version hoists its buffers the same way,
+    // fft/fft_gpu.cu:304-322)
     const size_t bytes = (size_t)rows * cols * sizeof(float);
-    FDR_HIP(hipMalloc((void**)&d_in, bytes));
-    if (hipMalloc((void**)&d_out, bytes) != hipSuccess) { (void)hipFree(d_in); return fail(FDR_ERR_ALLOC, "fdr_wiener_f32: hipMalloc"); }
+    if (p->stage_cap < bytes) {
+        (void)hipFree(p->stage_in); (void)hipFree(p->stage_out);
+        p->stage_in = p->stage_out = nullptr; p->stage_cap = 0;
+        const size_t cap = (size_t)p->M * p->N * sizeof(float);
+        if (hipMalloc((void**)&p->stage_in, cap) != hipSuccess || hipMalloc((void**)&p->stage_out, cap) != hipSuccess) {
+            (void)hipFree(p->stage_in); p->stage_in = nullptr;
+            return fail(FDR_ERR_ALLOC, "fdr_wiener_f32: hipMalloc of the staging buffers failed");
+        }
+        p->stage_cap = cap;
+    }
+    float *d_in = p->stage_in, *d_out = p->stage_out;
     hipError_t e = hipMemcpy2D(d_in, (size_t)cols * sizeof(float), img_host, (size_t)stride * sizeof(float),
                                (size_t)cols * sizeof(float), rows, hipMemcpyHostToDevice);
     int rc = FDR_OK;
@@ -741,7 +755,6 @@ int fdr_wiener_f32(fdr_plan* p, const float* img_host, int rows, int cols, int s
     if (e == hipSuccess && rc == FDR_OK)
         e = hipMemcpy2D(out_host, (size_t)out_stride * sizeof(float), d_out, (size_t)cols * sizeof(float),
                         (size_t)cols * sizeof(float), rows, hipMemcpyDeviceToHost);
-    (void)hipFree(d_in); (void)hipFree(d_out);
     if (rc != FDR_OK) return rc;
     FDR_HIP(e);
     return FDR_OK;

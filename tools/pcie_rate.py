@@ -15,7 +15,7 @@ with fdr.Plan(S, S, fdr.MODE_FAST) as p:
     for _ in range(n):
         p.wiener(img)
     dt = (time.perf_counter() - t0) / n
-    print("host-pointer path %dx%d: %.2f ms per image = %.0f Mpixels/s (pageable host memory, sync copies, hipMalloc per call)" % (S, S, dt * 1e3, S * S / 1e6 / dt))
+    print("host-pointer path %dx%d: %.2f ms per image = %.0f Mpixels/s (pageable host memory, synchronous copies)" % (S, S, dt * 1e3, S * S / 1e6 / dt))
     B = 16
     for label, alloc in (("pageable", lambda s: np.empty(s, np.float32)), ("pinned (fdr_host_alloc), DMA in place", fdr.host_alloc)):
         imgs = alloc((B, S, S)); out = alloc((B, S, S))
