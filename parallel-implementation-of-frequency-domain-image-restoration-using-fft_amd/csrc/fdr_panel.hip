@@ -587,7 +587,6 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_no
 #pragma unroll
                 for (int q = 0; q < Core::RHOL; ++q) {
                     const int s = u * Core::RHOL + q;
-                    constexpr int dummy = 0; (void)dummy;
                     const int c = u * T + (q << Core::LOGOUT);
 #ifdef FDR_DEBUG_SKIP_MEM
                     if (zk[r][0][s].x != 1.2345e-30f) continue;
