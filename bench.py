@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=4096, help="synthetic image edge (power of two)")
-    ap.add_argument("--batch", type=int, default=24, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=96, help="images per GPU per step")
     ap.add_argument("--mode", choices=["fast", "parity"], default="fast")
     ap.add_argument("--streams", type=int, default=0, help="internal streams / workspaces the batch alternates over (0 = 3, or 2 up to 2048^2)")
     ap.add_argument("--group", type=int, default=0, help="images per pass-B' launch (fast mode; 1..4, streams*group <= 8; 0 = 4 up to 2048^2, else 1)")
@@ -145,6 +145,10 @@ def main():
     def step():
         plan.wiener_batch_dev(imgs.data_ptr(), P, B, S, S, S, outs.data_ptr(), P, S, fdr.NORM_PADDED, stream=stream)
 
+    # one untimed priming step as part of the setup (code objects load and the internal streams / workspaces are touched
+    # on first use); the W warm-up steps of the contract follow inside timed_steps
+    step()
+    torch.cuda.synchronize()
     elapsed = batch_mod.timed_steps(comm, step, torch.cuda.synchronize, args.steps, args.warmup)
 
     # ---- per-kernel durations: hipEvent pairs on the launch stream, same K steps again ----
