@@ -137,6 +137,9 @@ int fdr_host_free(void* p);
 int fdr_wiener_batch_f32(fdr_plan* plan, const float* imgs_host, size_t img_pitch, int count,
                          int rows, int cols, int stride,
                          float* out_host, size_t out_pitch, int out_stride, int norm_area);
+/* the same with one pointer per image (the channel Mats of fft_gpu::wienerDeblur_RGB_*, fft/fft_gpu.cu:325-385) */
+int fdr_wiener_batch_ptrs_f32(fdr_plan* plan, const float* const* imgs_host, float* const* outs_host, int count,
+                              int rows, int cols, int stride, int out_stride, int norm_area);
 
 /* Batched mode only: let consecutive images of fdr_wiener_batch_f32_dev alternate over `nstreams`
  * (1..4) private workspaces on internal HIP streams, forked from / joined to the caller's stream,

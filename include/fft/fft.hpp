@@ -61,9 +61,25 @@ inline void wienerDeblur_RGB_optimized(std::vector<Mat>& channels, const Mat& ps
     FDR_CHECK(fdr_set_psf(plan, psfc.ptr<float>(0), psf.rows, psf.cols, psf.cols, K));
     auto t2 = high_resolution_clock::now();
     p.t_pre = getElapsedMs(t1, t2);
-    for (size_t i = 0; i < channels.size(); ++i) {
+    {   // all channels through the host batch pipeline: upload, restoration and download of consecutive channels overlap
+        // (what the stream + pinned-buffer set-up of fft/fft_gpu.cu:304-350 is after)
         auto a = high_resolution_clock::now();
-        channels[i] = run_channel(plan, channels[i]);
+        bool same = true;
+        for (const Mat& c : channels) same = same && c.rows == imgRows && c.cols == imgCols && c.type() == CV_32F;
+        if (same) {
+            std::vector<Mat> src, out;
+            std::vector<const float*> ins;
+            std::vector<float*> outs;
+            for (const Mat& c : channels) {
+                src.push_back(c.isContinuous() ? c : c.clone());
+                out.push_back(Mat(imgRows, imgCols, CV_32F));
+            }
+            for (size_t i = 0; i < channels.size(); ++i) { ins.push_back(src[i].ptr<float>(0)); outs.push_back(out[i].ptr<float>(0)); }
+            FDR_CHECK(fdr_wiener_batch_ptrs_f32(plan, ins.data(), outs.data(), (int)channels.size(), imgRows, imgCols, imgCols, imgCols, norm_ref()));
+            for (size_t i = 0; i < channels.size(); ++i) channels[i] = out[i];
+        } else {
+            for (size_t i = 0; i < channels.size(); ++i) channels[i] = run_channel(plan, channels[i]);
+        }
         p.t_compute += getElapsedMs(a, high_resolution_clock::now());
     }
     p.print("FAST (Reuse Memory)");

@@ -85,6 +85,7 @@ def _load():
     L.fdr_wiener_f32_dev.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, vp]
     L.fdr_wiener_batch_f32_dev.argtypes = [vp, vp, ctypes.c_size_t, ci, ci, ci, ci, vp, ctypes.c_size_t, ci, ci, vp]
     L.fdr_wiener_batch_f32.argtypes = [vp, vp, ctypes.c_size_t, ci, ci, ci, ci, vp, ctypes.c_size_t, ci, ci]
+    L.fdr_wiener_batch_ptrs_f32.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ci, ci, ci, ci, ci, ci]
     L.fdr_host_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
     L.fdr_host_free.argtypes = [vp]
     L.fdr_white_balance_u8.argtypes = [ci, ctypes.POINTER(vp), ctypes.POINTER(vp), ci, ci, ci, vp, ci]
@@ -100,7 +101,7 @@ def _load():
     L.fdr_plan_pass_times.argtypes = [vp, ctypes.POINTER(ci), _f32p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ci)]
     for name in ("fdr_device_count", "fdr_next_pow2", "fdr_is_pow2", "fdr_plan_create", "fdr_plan_destroy", "fdr_plan_dims",
                  "fdr_psf_motion", "fdr_psf_motion_dev", "fdr_set_psf", "fdr_set_psf_dev", "fdr_set_psf_motion",
-                 "fdr_wiener_f32", "fdr_wiener_f32_dev", "fdr_wiener_batch_f32_dev", "fdr_wiener_batch_f32", "fdr_host_alloc", "fdr_host_free",
+                 "fdr_wiener_f32", "fdr_wiener_f32_dev", "fdr_wiener_batch_f32_dev", "fdr_wiener_batch_f32", "fdr_wiener_batch_ptrs_f32", "fdr_host_alloc", "fdr_host_free",
                  "fdr_white_balance_u8", "fdr_white_balance_u8_dev", "fdr_plan_set_concurrency", "fdr_plan_set_batching",
                  "fdr_fft2d_c2c", "fdr_fft2d_c2c_dev", "fdr_fft1d_c2c", "fdr_dft_naive_c2c", "fdr_synth_image_dev", "fdr_plan_profile", "fdr_plan_pass_times"):
         getattr(L, name).restype = ci
@@ -112,7 +113,7 @@ lib = _load()
 EXPORTED_SYMBOLS = (
     "fdr_version", "fdr_last_error", "fdr_device_count", "fdr_next_pow2", "fdr_is_pow2", "fdr_plan_create",
     "fdr_plan_destroy", "fdr_plan_dims", "fdr_psf_motion", "fdr_psf_motion_dev", "fdr_set_psf", "fdr_set_psf_dev",
-    "fdr_set_psf_motion", "fdr_wiener_f32", "fdr_wiener_f32_dev", "fdr_wiener_batch_f32_dev", "fdr_wiener_batch_f32",
+    "fdr_set_psf_motion", "fdr_wiener_f32", "fdr_wiener_f32_dev", "fdr_wiener_batch_f32_dev", "fdr_wiener_batch_f32", "fdr_wiener_batch_ptrs_f32",
     "fdr_host_alloc", "fdr_host_free", "fdr_white_balance_u8", "fdr_white_balance_u8_dev", "fdr_plan_set_concurrency",
     "fdr_plan_set_batching", "fdr_fft2d_c2c",
     "fdr_fft2d_c2c_dev", "fdr_fft1d_c2c", "fdr_dft_naive_c2c", "fdr_synth_image_dev", "fdr_plan_profile",

@@ -777,6 +777,19 @@ int fdr_wiener_batch_f32(fdr_plan* p, const float* imgs_host, size_t img_pitch, 
     if (!p || !imgs_host || !out_host) return fail(FDR_ERR_ARG, "fdr_wiener_batch_f32: null argument");
     if (count < 0) return fail(FDR_ERR_ARG, "fdr_wiener_batch_f32: negative count");
     if (count == 0) return FDR_OK;
+    std::vector<const float*> ins((size_t)count);
+    std::vector<float*> outs((size_t)count);
+    for (int i = 0; i < count; ++i) { ins[i] = imgs_host + (size_t)i * img_pitch; outs[i] = out_host + (size_t)i * out_pitch; }
+    return fdr_wiener_batch_ptrs_f32(p, ins.data(), outs.data(), count, rows, cols, stride, out_stride, norm_area);
+}
+
+int fdr_wiener_batch_ptrs_f32(fdr_plan* p, const float* const* imgs_host, float* const* outs_host, int count, int rows, int cols,
+                              int stride, int out_stride, int norm_area) {
+    if (!p || !imgs_host || !outs_host) return fail(FDR_ERR_ARG, "fdr_wiener_batch_ptrs_f32: null argument");
+    if (count < 0) return fail(FDR_ERR_ARG, "fdr_wiener_batch_ptrs_f32: negative count");
+    if (count == 0) return FDR_OK;
+    for (int i = 0; i < count; ++i)
+        if (!imgs_host[i] || !outs_host[i]) return fail(FDR_ERR_ARG, "fdr_wiener_batch_ptrs_f32: null image pointer");
     if (!p->have_psf) return fail(FDR_ERR_STATE, "fdr_wiener: no PSF set on this plan (call fdr_set_psf* first)");
     if (rows <= 0 || cols <= 0 || rows > p->M || cols > p->N || stride < cols || out_stride < cols)
         return fail(FDR_ERR_ARG, "fdr_wiener_batch_f32: image shape does not fit the plan");
@@ -806,8 +819,8 @@ int fdr_wiener_batch_f32(fdr_plan* p, const float* imgs_host, size_t img_pitch, 
         if (!ok) break;
         for (int i = 0; i < count; ++i) {
             const int k = i % D;
-            const float* src = imgs_host + (size_t)i * img_pitch;
-            float* dst = out_host + (size_t)i * out_pitch;
+            const float* src = imgs_host[i];
+            float* dst = outs_host[i];
             // slot k is free again once image i-D has left the device (its D2H read d_out[k], its kernels read d_in[k])
             if (i >= D && bad(hipStreamWaitEvent(s_in, e_out[k], 0))) break;
             if (bad(hipMemcpy2DAsync(d_in[k], rowb, src, (size_t)stride * sizeof(float), rowb, rows, hipMemcpyHostToDevice, s_in)) ||
