@@ -148,3 +148,37 @@ inline void my_dft2D_forward(Mat& complexMat) { my_dft2D(complexMat, false); }
 inline void my_dft2D_inverse(Mat& complexMat) { my_dft2D(complexMat, true); }
 
 }  // namespace fft_gpu
+
+// fft/fft.hpp:9-18 of the reference: the serial back-end's names.  Here they run on the GPU in the PARITY mode, whose
+// FFT arithmetic is bit-identical to fft/fft_serial.cpp (per-stage twiddles replayed from its float recurrence, no FMA;
+// tests/test_gpu_parity.py holds the proof against the CPU restatement), so a serial.cpp-style caller gets the pixels
+// ./serial would give without a CPU path in this library.
+#include <complex>
+namespace fft_serial {
+
+inline void fft_radix2_inplace(std::vector<std::complex<float>>& a, bool inverse) {  // fft/fft_serial.cpp:40-68
+    if (a.empty()) return;
+    FDR_CHECK(fdr_fft1d_c2c(reinterpret_cast<float*>(a.data()), (int)a.size(), inverse ? 1 : 0, FDR_MODE_PARITY));
+}
+inline void dft_naive_inplace(std::vector<std::complex<float>>& a, bool inverse) {   // fft/fft_serial.cpp:71-87
+    if (a.empty()) return;
+    FDR_CHECK(fdr_dft_naive_c2c(reinterpret_cast<float*>(a.data()), (int)a.size(), inverse ? 1 : 0));
+}
+inline void transform_row_inplace(cv::Vec2f* rowPtr, int N, bool inverse) {          // fft/fft_serial.cpp:90-108
+    FDR_CHECK(fdr_fft1d_c2c(reinterpret_cast<float*>(rowPtr), N, inverse ? 1 : 0, FDR_MODE_PARITY));
+}
+inline void my_dft2D(Mat& complexMat, bool inverse) { fft_gpu::my_dft2D(complexMat, inverse); }  // :113-139 (parity plan)
+inline void my_dft2D_forward(Mat& complexMat) { my_dft2D(complexMat, false); }
+inline void my_dft2D_inverse(Mat& complexMat) { my_dft2D(complexMat, true); }
+// fft/fft_serial.cpp:141-261: img is the (already padded) channel; the result has img's size, normalised over all of it
+inline Mat wienerDeblur_myfft(const Mat& img, const Mat& psf, float K) {
+    const int mode = fft_gpu::mode_ref(), area = fft_gpu::norm_ref();
+    fft_gpu::set_mode(FDR_MODE_PARITY);
+    fft_gpu::set_norm_area(FDR_NORM_PADDED);
+    Mat out = fft_gpu::wienerDeblur_myfft(img, psf, K);
+    fft_gpu::set_mode(mode);
+    fft_gpu::set_norm_area(area);
+    return out;
+}
+
+}  // namespace fft_serial

@@ -452,6 +452,33 @@ def test_drop_in_cli(fdr, tmp_path):
     assert bad.returncode == 255 and "Cannot read image" in bad.stdout
 
 
+def test_serial_style_cli_gives_the_serial_pixels(fdr, oracle, tmp_path):
+    """tools/cli/serial (the reference's serial driver contract, BASELINE config 1, on the GPU parity mode): its
+    restored planes are bit-identical to the CPU restatement of ./serial wrapped as serial.cpp:34-39 does (pad to
+    powers of two, normalise over the padded area, crop), and it prints the reference driver's lines."""
+    import subprocess
+    from PIL import Image
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", _os.path.join(root, "tools", "cli"), "-s", "serial"])
+    png = _os.path.join(root, "tests", "golden", "car_blurred.png")
+    out_png, out_raw = str(tmp_path / "car_serial.png"), str(tmp_path / "car_serial.f32")
+    r = subprocess.run([_os.path.join(root, "tools", "cli", "serial"), png, "40", "45", "--out", out_png, "--raw-out", out_raw],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Deblurring 3 channels took(serial):" in r.stdout and "Total program time:" in r.stdout
+    rgb = np.asarray(Image.open(png).convert("RGB"), dtype=np.float32) / 255.0
+    h, w = rgb.shape[:2]
+    planes = np.fromfile(out_raw, dtype=np.float32).reshape(3, h, w)  # B, G, R
+    psf = oracle.motion_blur_kernel(40, 45.0)
+    for k, ch in enumerate((2, 1, 0)):
+        _assert_same(planes[k], oracle.serial_channel(np.ascontiguousarray(rgb[:, :, ch]), psf, 0.01), "serial CLI plane %d vs oracle" % k)
+    res = np.asarray(Image.open(out_png))
+    assert res.shape == (h, w, 3) and res.dtype == np.uint8
+    assert subprocess.run([_os.path.join(root, "tools", "cli", "serial")], capture_output=True).returncode == 255
+    bad = subprocess.run([_os.path.join(root, "tools", "cli", "serial"), "/nonexistent.png", "40", "45"], capture_output=True, text=True)
+    assert bad.returncode == 255 and "Cannot read image" in bad.stdout
+
+
 def test_cpp_shim_surface(fdr, oracle, tmp_path):
     """tools/cli/shim_test.cpp calls every name of the drop-in C++ surface (namespace fft_gpu of fft/fft.hpp:31-45 and
     the utils.hpp helpers) the way a caller of the reference would; its dumps must equal what the Python binding of
