@@ -105,20 +105,12 @@ struct PolicyFast {
         // 30 % fewer VALU instructions per transform, 1.37 -> 1.03 us per 4096-point transform per CU.  The rotated
         // twiddle (-w.y, w.x) is a register pair per twiddle; building it from operand modifiers instead (negated
         // broadcast of v.y) costs a v_mov per butterfly and was slower.
-#ifndef FDR_SCALAR_BFLY
         const v2f uu = {u.x, u.y}, vx = {v.x, v.x}, vy = {v.y, v.y}, ww = {w.x, w.y}, wr = {-w.y, w.x};
         const v2f t = __builtin_elementwise_fma(vy, wr, uu);   // (u.x - v.y w.y, u.y + v.y w.x)
         const v2f a = __builtin_elementwise_fma(vx, ww, t);    // (.. + v.x w.x, .. + v.x w.y)
         const v2f two = {2.0f, 2.0f};
         const v2f b = __builtin_elementwise_fma(two, uu, -a);
         u.x = a.x; u.y = a.y; v.x = b.x; v.y = b.y;
-#else
-        const float ar = __builtin_fmaf(v.x, w.x, __builtin_fmaf(-v.y, w.y, u.x));
-        const float ai = __builtin_fmaf(v.x, w.y, __builtin_fmaf(v.y, w.x, u.y));
-        v.x = __builtin_fmaf(2.0f, u.x, -ar);
-        v.y = __builtin_fmaf(2.0f, u.y, -ai);
-        u.x = ar; u.y = ai;
-#endif
     }
     static __device__ __forceinline__ float2 csq(float2 a) {
         return make_float2(__builtin_fmaf(a.x, a.x, -(a.y * a.y)), 2.0f * a.x * a.y);
@@ -151,6 +143,19 @@ struct PolicyFast {
             t.w1 = csq(t.w2a);
         }
         return t;
+    }
+};
+
+// The same with scalar FMAs (what hipcc packs by itself): the 4096-point column pass keeps 128 data registers per lane,
+// where the extra register pair per rotated twiddle of the packed form spills (14 VGPRs, +15 % HBM traffic from scratch)
+// for no gain in time -- that kernel alone uses this variant.
+struct PolicyFastScalar : PolicyFast {
+    static __device__ __forceinline__ void bfly(float2& u, float2& v, const float2 w) {
+        const float ar = __builtin_fmaf(v.x, w.x, __builtin_fmaf(-v.y, w.y, u.x));
+        const float ai = __builtin_fmaf(v.x, w.y, __builtin_fmaf(v.y, w.x, u.y));
+        v.x = __builtin_fmaf(2.0f, u.x, -ar);
+        v.y = __builtin_fmaf(2.0f, u.y, -ai);
+        u.x = ar; u.y = ai;
     }
 };
 
@@ -207,10 +212,9 @@ __device__ __forceinline__ void radix_step(float2* x, const TwSet& t) {
 // {1, -+i};  stage 4: w {1, e^(-+i pi/8), e^(-+i pi/4), e^(-+3i pi/8)} x {1, -+i}.  Pair (i, i + 16/2^t) of block j
 // uses T_{2^t LP}[k + LP bitrev(j)], exactly the radix-8 scheme one level deeper; outputs leave in bit-reversed
 // order and are put back by six swaps.
-template <int B, int V, bool INV>
+template <class P, int B, int V, bool INV>
 __device__ __forceinline__ void radix16_fast(float2 (&v)[B][V], float2 base) {
     static_assert(V == 16, "16 values per thread");
-    using P = PolicyFast;
     asm volatile("" : "+v"(base.x), "+v"(base.y));  // as in PolicyFast::twiddles: keep the derived set out of LICM's reach
     const float2 w = INV ? make_float2(base.x, -base.y) : base;
     auto rot = [](float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); };  // times -+i
@@ -315,7 +319,7 @@ struct FftCore {
         constexpr int LR = St::lr(J), NU = St::nu(J), RHO = 1 << LR, LOGR = St::logR(J), LP = 1 << St::lprev(J);
         if constexpr (LR == 4) {
             static_assert(Pol::kHoist, "radix-16 steps exist for the fast policy only");
-            radix16_fast<B, V, INV>(v, bs.b[J][0]);  // NU == 1: the 16 values of a thread are one butterfly
+            radix16_fast<Pol, B, V, INV>(v, bs.b[J][0]);  // NU == 1: the 16 values of a thread are one butterfly
         } else {
 #pragma unroll
             for (int u = 0; u < NU; ++u) {

@@ -20,6 +20,7 @@
 //   pass C' : 4 rows gathered from the panels -> row IFFTs -> real plane + min/max partial
 // The layout is private to a plan (never visible through the C ABI); W is stored the same way.
 #include "fdr_fft_core.hpp"
+#include <type_traits>
 #include "fdr_kernels.hpp"
 
 namespace fdr {
@@ -1248,7 +1249,7 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
     const int npanels, const int ntiles, const int packed0) {
     using St = Steps<LOGM, 4>;
     constexpr int G = Panel16Geom<LOGM>::G, T = St::T, M = St::L, V = 16;
-    using Core = FftCore<LOGM, 4, 2, PolicyFast, 4>;
+    using Core = FftCore<LOGM, 4, 2, typename std::conditional<LOGM == 12, PolicyFastScalar, PolicyFast>::type, 4>;  // see PolicyFastScalar
     __shared__ float2 lds[G * 2 * St::BUF];
     const int g = G == 1 ? 0 : (int)(threadIdx.x >> St::LOGT);
     const int tid = threadIdx.x & (T - 1);
