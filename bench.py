@@ -62,18 +62,39 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals on a one-GPU box)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-size", type=int, default=0, help="edge of the CPU-baseline sample (default: --size, capped at 4096)")
+    ap.add_argument("--repeats", type=int, default=5, help="repetitions of the K timed steps; value = median (SURVEY 8d)")
+    ap.add_argument("--total-batch", type=int, default=0,
+                    help="strong scaling: a FIXED batch of T images per step sharded over the ranks by calculate_distribution "
+                         "(fft/fft_mpi.cpp:89-100), e.g. BASELINE config 5: --size 2048 --total-batch 512; 0 = weak scaling with --batch per GPU")
+    ap.add_argument("--no-psf-recompute", action="store_true", help="skip the second figure (PSF spectrum rebuilt per image)")
     return ap.parse_args()
 
 
 def cpu_baseline(size):
-    """Oracle (kind 'port'), one thread: as many size x size single-channel images as fit ~12 s."""
+    """Oracle (kind 'port'), one thread PINNED to one core (taskset -c 0): as many size x size
+    single-channel images as fit ~12 s.  Returns (json object, restored image 0) -- image 0 also serves as the
+    reference of the GPU-vs-CPU error figures of the bench line."""
     from oracle import oracle as o
     o.build()
+    old_aff = None
+    try:
+        old_aff = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, {min(old_aff)})
+    except (AttributeError, OSError):
+        old_aff = None
+    try:
+        return _cpu_baseline_pinned(o, size, min(old_aff) if old_aff else None)
+    finally:
+        if old_aff:
+            os.sched_setaffinity(0, old_aff)
+
+
+def _cpu_baseline_pinned(o, size, core):
     psf = o.motion_blur_kernel(50, 30.0)
     P = size * size
     img = o.synth_image(SEEDS.get(size, 0x5EED0000), 0, P).reshape(size, size)
     t0 = time.perf_counter()
-    o.serial_channel(img, psf, 0.01)
+    ref0 = o.serial_channel(img, psf, 0.01)
     first = time.perf_counter() - t0
     extra = max(0, min(7, int(12.0 / first) - 1))
     more = [o.synth_image(SEEDS.get(size, 0x5EED0000), (b + 1) * P, P).reshape(size, size) for b in range(extra)]
@@ -84,9 +105,9 @@ def cpu_baseline(size):
     n = 1 + extra
     return {
         "value": round(n * P / 1e6 / dt, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-        "sample": "%d image(s) %dx%d fp32, PSF 50/30deg, K=0.01, oracle/fdr_oracle.c (gcc -O2, no FMA), %.1f s on 1 of %d host cores"
-                  % (n, size, size, dt, os.cpu_count() or 0),
-    }
+        "sample": "%d image(s) %dx%d fp32, PSF 50/30deg, K=0.01, oracle/fdr_oracle.c (gcc -O2, no FMA), %.1f s on 1 of %d host cores%s"
+                  % (n, size, size, dt, os.cpu_count() or 0, (", pinned to core %d" % core) if core is not None else ""),
+    }, ref0
 
 
 def main():
@@ -112,18 +133,17 @@ def main():
     comm = batch_mod.Comm(backend=args.backend, device=dev)
     rank, world = comm.rank, comm.world
 
-    S, B = args.size, args.batch
+    S = args.size
     mode = fdr.MODE_FAST if args.mode == "fast" else fdr.MODE_PARITY
     P = S * S
     seed = SEEDS.get(S, 0x5EED0000)
+    if args.total_batch > 0:   # strong scaling: a fixed batch sharded by the reference's own distribution rule
+        counts, displs = batch_mod.calculate_distribution(args.total_batch, world)
+        B, first_image, scaling = counts[rank], displs[rank], "strong"
+    else:                      # weak scaling: every rank restores --batch images per step
+        B, first_image, scaling = args.batch, rank * args.batch, "weak"
 
-    flags = fdr.FLAG_NO_PIPELINE if os.environ.get("FDR_NO_PIPELINE") == "1" else 0
-    if os.environ.get("FDR_FULL_SPECTRUM") == "1":
-        flags |= fdr.FLAG_FULL_SPECTRUM
-    if os.environ.get("FDR_LEAN_COLS") == "1":
-        flags |= fdr.FLAG_LEAN_COLS
-    if os.environ.get("FDR_COLS8") == "1":
-        flags |= fdr.FLAG_COLS8
+    flags = fdr.FLAG_FULL_SPECTRUM if os.environ.get("FDR_FULL_SPECTRUM") == "1" else 0
     if os.environ.get("FDR_FUSED_NORM") == "1":
         flags |= fdr.FLAG_FUSED_NORM
     spectrum = "half" if (args.mode == "fast" and not (flags & fdr.FLAG_FULL_SPECTRUM) and S >= 32) else "full"
@@ -136,22 +156,55 @@ def main():
         args.group = max(1, min(4, 8 // args.streams)) if S <= 2048 else 1
     plan.set_batching(args.streams, args.group if args.mode == "fast" else 1)
     plan.set_psf_motion(50, 30.0, 0.01, stream=stream)  # PSF generated, padded and transformed on the device
-    imgs = torch.empty((B, S, S), dtype=torch.float32, device=dev)
-    outs = torch.empty((B, S, S), dtype=torch.float32, device=dev)
-    # image b of rank r is global image r*B + b of the counter-based generator (distinct per rank)
-    fdr.synth_image_dev(imgs.data_ptr(), B * P, seed, first_index=rank * B * P, device=local_rank, stream=stream)
+    imgs = torch.empty((max(B, 1), S, S), dtype=torch.float32, device=dev)
+    outs = torch.zeros((max(B, 1), S, S), dtype=torch.float32, device=dev)
+    # image b of this rank is global image first_image + b of the counter-based generator (distinct per rank)
+    if B > 0:
+        fdr.synth_image_dev(imgs.data_ptr(), B * P, seed, first_index=first_image * P, device=local_rank, stream=stream)
     torch.cuda.synchronize()
 
     def step():
         plan.wiener_batch_dev(imgs.data_ptr(), P, B, S, S, S, outs.data_ptr(), P, S, fdr.NORM_PADDED, stream=stream)
 
     # one untimed priming step as part of the setup (code objects load and the internal streams / workspaces are touched
-    # on first use); the W warm-up steps of the contract follow inside timed_steps
+    # on first use); the W warm-up steps of the contract follow inside timed_steps.  The K timed steps are repeated
+    # `--repeats` times (each repetition bracketed by barrier + synchronize, MAX over ranks); `value` is the median.
     step()
     torch.cuda.synchronize()
-    elapsed = batch_mod.timed_steps(comm, step, torch.cuda.synchronize, args.steps, args.warmup)
+    reps = []
+    for r in range(max(1, args.repeats)):
+        reps.append(batch_mod.timed_steps(comm, step, torch.cuda.synchronize, args.steps, args.warmup if r == 0 else 0))
+    elapsed = sorted(reps)[len(reps) // 2]
 
-    # ---- per-kernel durations: hipEvent pairs on the launch stream, same K steps again ----
+    # ---- consistency check over RCCL (outside the timed region) ----
+    images_mine = B * args.steps  # images this rank restored in one repetition of the timed region
+    if B > 0:
+        chk = float(outs[:B].double().sum().item())
+        finite = bool(torch.isfinite(outs[:B]).all().item())
+        omin, omax = float(outs[:B].min().item()), float(outs[:B].max().item())
+        # every image is min-max normalised over its whole (padded = full) plane: each must span [0, 1]
+        spans = bool(((outs[:B].amin(dim=(1, 2)) <= 1e-6) & (outs[:B].amax(dim=(1, 2)) > 1.0 - 1e-6)).all().item())
+        ok = finite and omin >= 0.0 and omax <= 1.0 and spans
+    else:
+        chk, ok = 0.0, True
+    tot = comm.allreduce_sum([images_mine, chk, 1.0 if ok else 0.0, B])
+    out0 = outs[0].cpu().numpy() if (rank == 0 and B > 0) else None
+
+    # ---- second figure: the PSF spectrum rebuilt for every image, as the reference's loop does per channel
+    #      (fft/fft_gpu.cu:329-343,356): PSF generation + pad + 2-D FFT + filter inside the step, one stream ----
+    psf_elapsed = None
+    if not args.no_psf_recompute and B > 0:
+        nb = min(B, 16)
+
+        def step_psf():
+            for b in range(nb):
+                plan.set_psf_motion(50, 30.0, 0.01, stream=stream)
+                plan.wiener_dev(imgs[b].data_ptr(), S, S, S, outs[b].data_ptr(), S, fdr.NORM_PADDED, stream=stream)
+
+        psf_elapsed = batch_mod.timed_steps(comm, step_psf, torch.cuda.synchronize, args.steps, 1)
+        psf_images = comm.allreduce_sum([nb * args.steps])[0]
+
+    # ---- per-kernel durations: hipEvent pairs on the launch stream, same K steps again (one stream: un-overlapped) ----
     plan.profile(True)
     for _ in range(args.steps):
         step()
@@ -159,14 +212,9 @@ def main():
     passes = plan.pass_times()
     plan.profile(False)
 
-    # ---- consistency check over RCCL (outside the timed region) ----
-    chk = float(outs.double().sum().item())
-    finite = bool(torch.isfinite(outs).all().item())
-    omin, omax = float(outs.min().item()), float(outs.max().item())
-    tot = comm.allreduce_sum([B * args.steps, chk, 1.0 if (finite and omin >= 0.0 and omax <= 1.0) else 0.0])
-
+    rc = 0
     if rank == 0:
-        images = world * B * args.steps
+        images = int(tot[0])
         value = images * P / 1e6 / elapsed
         # bytes per pixel of the passes that actually ran (the fused C'E pass drops the raw-plane round trip)
         base_names = {n.rsplit(" [", 1)[0] if n.endswith(" images]") else n for n, _, _ in passes}
@@ -176,7 +224,7 @@ def main():
         roofline = None
         if dom:
             name, ms, cnt = dom
-            # a grouped pass-B' launch ("... [k images]") moves k images' worth of bytes
+            # a grouped launch ("... [k images]") moves k images' worth of bytes
             base_name, nimg = name, 1
             if name.endswith(" images]"):
                 base_name, tail = name.rsplit(" [", 1)
@@ -189,6 +237,9 @@ def main():
                 "kernel": name, "kernel_ms": round(ms, 5), "launches_timed": cnt,
                 "algorithmic_bytes_per_launch": alg,
                 "all_passes_ms": {n: round(m, 5) for n, m, _ in passes},
+                "all_passes_frac": {n: round(PASS_BYTES[spectrum].get(n.rsplit(" [", 1)[0] if n.endswith(" images]") else n, 0) * P
+                                             * (int(n.rsplit(" [", 1)[1].split()[0]) if n.endswith(" images]") else 1)
+                                             / (m * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) for n, m, _ in passes if m > 0},
                 "pipeline": {"bytes_per_pixel": pipe_bpp, "achieved": round(pipe_gbps, 1),
                              "frac": round(pipe_gbps / HBM_PEAK_GBPS, 4),
                              "full_complex_equivalent_GBps": round(PIPELINE_BYTES[(args.mode, "full")] * P * images / elapsed / 1e9, 1)},
@@ -202,26 +253,46 @@ def main():
                         roofline["traffic"] = tj[key][base_name] * nimg
                 except Exception:
                     pass
+        vals = sorted(images * P / 1e6 / t for t in reps)
+        config = {"workload": "%dx%d synthetic fp32, PSF len=50 angle=30, K=0.01, single channel, device-resident" % (S, S),
+                  "images_per_step": int(tot[3]), "images_per_gpu_per_step": B if scaling == "weak" else None,
+                  "total_batch": args.total_batch or None,
+                  "mode": args.mode, "spectrum": spectrum, "streams": args.streams, "images_per_launch": args.group,
+                  "parallelism": "images sharded over %d rank(s), no data-path collective" % world,
+                  "normalize_area": "padded (serial semantics)",
+                  "repeats": len(reps), "value_min": round(vals[0], 1), "value_max": round(vals[-1], 1),
+                  "value_with_psf_recompute": round(psf_images * P / 1e6 / psf_elapsed, 1) if psf_elapsed else None}
         line = {
             "metric": "Mpixels/sec restored (FFT+Wiener+IFFT) at %dx%d fp32" % (S, S),
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%dx%d synthetic fp32, PSF len=50 angle=30, K=0.01, single channel, device-resident" % (S, S),
-                       "images_per_gpu_per_step": B, "mode": args.mode, "spectrum": spectrum, "streams": args.streams, "images_per_B_launch": args.group, "parallelism": "images sharded over %d rank(s)" % world,
-                       "normalize_area": "padded (serial semantics)"},
+            "config": config,
             "roofline": roofline,
-            "check": {"images_done": int(tot[0]), "checksum": tot[1], "ranks_ok": int(tot[2])},
+            "check": {"images_done": images, "images_expected": int(tot[3]) * args.steps, "checksum": tot[1], "ranks_ok": int(tot[2]),
+                      "ranks": world},
         }
+        if int(tot[2]) != world or images != int(tot[3]) * args.steps:
+            rc = 3
         if world == 1 and not args.no_cpu_baseline:
             cs = args.cpu_size or min(S, 4096)
-            line["cpu_baseline"] = cpu_baseline(cs)
+            line["cpu_baseline"], ref0 = cpu_baseline(cs)
+            if cs == S and out0 is not None:
+                # GPU image 0 against the CPU oracle's image 0: the stated tolerance is 1e-4
+                import numpy as np
+                d = (out0.astype(np.float64) - ref0.astype(np.float64))
+                line["parity"] = {"against": "oracle image 0 (serial path restatement)", "max_abs": float(np.abs(d).max()),
+                                  "rel_l2": float(np.linalg.norm(d) / np.linalg.norm(ref0.astype(np.float64))), "tolerance": 1e-4}
+                if not (line["parity"]["max_abs"] <= 1e-4 and line["parity"]["rel_l2"] <= 1e-4):
+                    rc = 4
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
 
     plan.close()
     comm.close()
+    if rc:
+        sys.exit(rc)  # the consistency check or the parity check failed: the line above says which
 
 
 if __name__ == "__main__":

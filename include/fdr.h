@@ -20,14 +20,15 @@
 extern "C" {
 #endif
 
-#define FDR_VERSION 100 /* 0.1.0 */
+#define FDR_VERSION 200 /* 0.2.0 */
 
 /* status codes (reference: CHECK_CUDA prints and exit(1)s, fft/fft_gpu.cu:59-66; the C++ shim
  * reproduces that on any non-zero status) */
 #define FDR_OK 0
 #define FDR_ERR_ARG (-1)      /* null pointer, non-positive size, PSF larger than the plan ... */
 #define FDR_ERR_NOT_POW2 (-2) /* plan dimensions must be powers of two (callers pad first,
-                                 as fft/fft_gpu.cu:287-288 and serial.cpp:36 do)            */
+                                 as fft/fft_gpu.cu:287-288 and serial.cpp:36 do) unless
+                                 FDR_FLAG_ANY_SIZE asks for the reference's naive-DFT path  */
 #define FDR_ERR_HIP (-3)      /* a HIP runtime call failed; message holds hipGetErrorString  */
 #define FDR_ERR_STATE (-4)    /* e.g. fdr_wiener_* before fdr_set_psf*                        */
 #define FDR_ERR_ALLOC (-5)
@@ -43,36 +44,22 @@ extern "C" {
 #define FDR_FLAG_SIMPLE_PATH 1u /* reference-shaped kernels: row FFT, transpose, row FFT, transpose
                                    (fft/fft_gpu.cu:214-240); slow, used as an on-device cross-check */
 
-#define FDR_FLAG_NO_PIPELINE 2u /* fast mode: one workgroup per column tile instead of the persistent,
-                                   register-double-buffered pass B' (A/B comparison and debugging)  */
-
-#define FDR_FLAG_ROWMAJOR 4u    /* fast mode: keep the intermediate spectrum row-major (32-byte column
-                                   tiles) instead of panel-major; slower, kept for A/B measurements   */
-
-#define FDR_FLAG_NO_PACKING 8u  /* fast mode: one complex row transform per row instead of two real /
-                                   Hermitian rows per transform (A/B measurements)                    */
-
-#define FDR_FLAG_POW2_PANELS 16u /* fast mode: panel stride exactly 4*M elements (no channel skew; A/B) */
-
-#define FDR_FLAG_FULL_SPECTRUM 32u /* fast mode: keep all N columns of the (Hermitian) spectrum instead of
-                                      N/2 + 1 (A/B measurements; implied by NO_PACKING and ROWMAJOR)     */
-
-#define FDR_FLAG_LEAN_COLS 64u /* fast mode: pass B' with one register set and one workgroup per column tile, two
-                                  workgroups per CU (the hardware overlaps one tile's memory phases with the other's
-                                  transforms) instead of the persistent software-pipelined kernel (A/B measurements;
-                                  always used for 8192-point columns)                                              */
+#define FDR_FLAG_FULL_SPECTRUM 32u /* fast mode: keep all N columns of the (Hermitian) spectrum instead of the
+                                      non-redundant half (the complex-to-complex byte count of SURVEY.md 8d)     */
 
 #define FDR_FLAG_FUSED_NORM 128u /* fast mode: pass C' (rows inverse + min/max) and pass E (normalise + crop) as ONE launch
                                     that keeps the raw plane in registers across a grid-wide min/max hand-off (-8 bytes
                                     per pixel; images of at most 4 row groups per CU, i.e. up to 4096 x 4096 on 256 CUs).
                                     Opt-in: a fused launch occupies every CU while it waits, so it does not overlap with
                                     other images' passes in the batched multi-stream mode, where the two-launch form is
-                                    faster (measured: DESIGN.md section 5).                                           */
+                                    faster (measured: DESIGN.md section 5).  The wait is bounded (FDR_OPT_FUSED_SPIN_LIMIT);
+                                    a workgroup whose wait runs out writes raw rows that a fix-up launch normalises.      */
 
-#define FDR_FLAG_COLS8 256u /* fast mode, columns of 1024 points and more: the radix-8 persistent kernel (8 values per
-                               thread, one 512-thread workgroup per CU, software-pipelined) instead of the default
-                               pass B' with 16 values per thread (radix-16 steps: a 4-column tile is one 256-thread
-                               workgroup, two of which share a CU).  A/B measurements.                            */
+#define FDR_FLAG_ANY_SIZE 512u /* accept plan dimensions that are not powers of two: such a dimension is transformed by
+                                  the O(n^2) DFT of fft_serial::dft_naive_inplace (fft/fft_serial.cpp:71-87), as
+                                  transform_row_inplace dispatches (:100-101) when wienerDeblur_myfft pads to
+                                  getOptimalDFTSize (2^a 3^b 5^c, :153-154) instead of to a power of two.  Reference-shaped
+                                  passes (rows, transpose, rows, transpose); both modes use the parity arithmetic.        */
 
 /* normalisation area selector for fdr_wiener_* */
 #define FDR_NORM_PADDED 1  /* serial semantics: min/max over the padded M x N area, then crop
@@ -91,12 +78,19 @@ int fdr_device_count(int* count);
 int fdr_next_pow2(int n);
 int fdr_is_pow2(int n);
 
+/* -- cv::getOptimalDFTSize as fft/fft_serial.cpp:153-154 uses it: smallest 2^a 3^b 5^c >= n -- */
+int fdr_optimal_dft_size(int n);
+
 /* -- plan: owns twiddle tables, the M x N complex workspace, the filter spectrum and the
  *    min/max scratch for one device.  Replaces the per-call cudaMalloc/cudaFree block of
  *    fft/fft_gpu.cu:304-322,389-393.  One host thread at a time per plan.               */
 int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan** out);
 int fdr_plan_destroy(fdr_plan* plan);
 int fdr_plan_dims(const fdr_plan* plan, int* M, int* N, int* mode);
+/* tunables of a plan */
+#define FDR_OPT_FUSED_SPIN_LIMIT 1 /* FDR_FLAG_FUSED_NORM: sweeps (about 0.5 us each) a workgroup waits for the other
+                                      workgroups' min/max before it falls back to the two-launch form; default 20000 */
+int fdr_plan_set_option(fdr_plan* plan, int option, long long value);
 
 /* -- PSF generation: utils.hpp:15-24 motionBlurKernel(size, angle) ------------------- */
 /* host result, size*size floats (computed on the device by the psf kernel, copied back) */
@@ -146,9 +140,9 @@ int fdr_wiener_batch_ptrs_f32(fdr_plan* plan, const float* const* imgs_host, flo
  * so one image's kernel tails overlap the next image's kernel heads.  Costs (nstreams-1) extra
  * workspaces of 12 bytes per padded pixel.  Default 1.                                         */
 int fdr_plan_set_concurrency(fdr_plan* plan, int nstreams);
-/* The same with `group` (1..4) images per pass-B' launch in the fast mode: the persistent column kernel then
- * walks the panels of `group` images in one go (its prologue / epilogue amortise, and small images fill the
- * chip).  nstreams * group <= 8 workspaces.  fdr_plan_set_concurrency(n) == fdr_plan_set_batching(n, 1).   */
+/* The same with `group` (1..4) images per launch in the fast mode: every pass handles `group` images in one launch
+ * (small images are launch bound; one launch per pass and group fills the chip).
+ * nstreams * group <= 8 workspaces.  fdr_plan_set_concurrency(n) == fdr_plan_set_batching(n, 1).              */
 int fdr_plan_set_batching(fdr_plan* plan, int nstreams, int group);
 
 /* -- fft_gpu::my_dft2D(Mat&, bool) (fft/fft.hpp:40; empty body at fft/fft_gpu.cu:515):
@@ -183,6 +177,72 @@ int fdr_synth_image_dev(int device, uint64_t seed, uint64_t first_index, size_t 
 #define FDR_MAX_PASSES 16
 int fdr_plan_profile(fdr_plan* plan, int enable);
 int fdr_plan_pass_times(fdr_plan* plan, int* n_passes, float* mean_ms, const char** names, int* launches);
+
+/* -- the six buckets of the reference's Profiler (fft/fft_gpu.cu:17-57: alloc / h2d / pre / compute / d2h / post),
+ *    accumulated per plan since its creation (or the last reset) from hipEvent pairs on the streams the work ran on:
+ *      ALLOC   host wall time of fdr_plan_create (hipMalloc is synchronous)      [fft_gpu.cu:304-322]
+ *      H2D     image / PSF uploads of the host-pointer entry points              [:330-335,346-350]
+ *      PRE     PSF generation, padding, PSF spectrum and filter (fdr_set_psf*)   [:337-343,356]
+ *      COMPUTE the restoration passes of fdr_wiener_*                            [:354-369]
+ *      D2H     result downloads of the host-pointer entry points                 [:372-375]
+ *      POST    0 here: normalisation runs on the device inside COMPUTE           [:378-384 is a CPU cv::normalize]
+ *    In the pipelined host batch (fdr_wiener_batch_*_f32) the three streams overlap, so H2D + COMPUTE + D2H exceeds the
+ *    wall time, exactly as per-phase sums do.  The call synchronises the device.                                       */
+#define FDR_PHASE_ALLOC 0
+#define FDR_PHASE_H2D 1
+#define FDR_PHASE_PRE 2
+#define FDR_PHASE_COMPUTE 3
+#define FDR_PHASE_D2H 4
+#define FDR_PHASE_POST 5
+#define FDR_N_PHASES 6
+int fdr_plan_phase_times(fdr_plan* plan, float ms[FDR_N_PHASES], int reset);
+
+/* -- the multi-GPU batched mode for C and C++ callers: `count` independent images sharded over
+ *    `n_devices` devices of this process, contiguous blocks by the reference's calculate_distribution rule
+ *    (fft/fft_mpi.cpp:89-100 applied to images: count[g] = count / G + (g < count % G)), one host thread, one plan and
+ *    one PSF spectrum per entry of `devices` (an ordinal may repeat: {0, 0} runs two workers on device 0).  No data-path
+ *    collective: images are independent.
+ *      imgs_host != NULL: image i is read from imgs_host[i] and its result written to outs_host[i] (rows x cols,
+ *                         strides in elements) through the pipelined host batch of each worker;
+ *      imgs_host == NULL: device-resident synthetic run (BASELINE config 5 shape): every worker generates its shard with
+ *                         fdr_synth_image_dev (global image index = position in the batch), restores it `steps` times
+ *                         (after `warmup` untimed passes) and keeps the results on its device; only statistics return.
+ *    psf_host == NULL: motionBlurKernel(psf_size, psf_angle_deg) generated on each device.                            */
+typedef struct fdr_batch_desc {
+    int n_devices;
+    const int* devices;
+    int M, N;            /* plan dimensions (powers of two) */
+    int mode;            /* FDR_MODE_* */
+    unsigned flags;      /* FDR_FLAG_* */
+    const float* psf_host;
+    int psf_rows, psf_cols, psf_stride;
+    int psf_size;        /* used when psf_host == NULL */
+    double psf_angle_deg;
+    float K;
+    int count;           /* images in the batch */
+    int rows, cols;      /* image size, rows <= M, cols <= N */
+    int stride, out_stride;
+    const float* const* imgs_host;
+    float* const* outs_host;
+    uint64_t synth_seed; /* synthetic run */
+    int steps, warmup;   /* synthetic run: timed / untimed passes over the shard (steps >= 1) */
+    int nstreams, group; /* fdr_plan_set_batching of every worker (0, 0 = defaults) */
+    int norm_area;       /* FDR_NORM_* */
+} fdr_batch_desc;
+
+#define FDR_BATCH_MAX_DEVICES 16
+typedef struct fdr_batch_stats {
+    int n_devices;
+    int first[FDR_BATCH_MAX_DEVICES];      /* first image of worker g */
+    int images[FDR_BATCH_MAX_DEVICES];     /* images of worker g (per pass) */
+    double elapsed_ms[FDR_BATCH_MAX_DEVICES]; /* worker g: wall time of its timed region */
+    double checksum[FDR_BATCH_MAX_DEVICES];   /* sum of worker g's restored pixels (last pass) */
+    int status[FDR_BATCH_MAX_DEVICES];     /* FDR_OK or the failing status of worker g */
+    double wall_ms;                        /* all workers: from the common start to the last one's finish */
+    long long images_done;                 /* sum over workers of images x passes */
+    double mpixels_per_s;                  /* images_done * rows * cols / wall_ms */
+} fdr_batch_stats;
+int fdr_batch_run(const fdr_batch_desc* desc, fdr_batch_stats* stats);
 
 #ifdef __cplusplus
 }

@@ -21,19 +21,36 @@ LIB_PATH = os.environ.get("FDR_LIB_PATH") or os.path.join(_HERE, "libfdr.so")
 MODE_PARITY = 0
 MODE_FAST = 1
 FLAG_SIMPLE_PATH = 1
-FLAG_NO_PIPELINE = 2
-FLAG_ROWMAJOR = 4
-FLAG_NO_PACKING = 8
-FLAG_POW2_PANELS = 16
 FLAG_FULL_SPECTRUM = 32
-FLAG_LEAN_COLS = 64
 FLAG_FUSED_NORM = 128
-FLAG_COLS8 = 256
+FLAG_ANY_SIZE = 512
 NORM_PADDED = 1
 NORM_CROPPED = 0
 MAX_PASSES = 16
+OPT_FUSED_SPIN_LIMIT = 1
+PHASES = ("alloc", "h2d", "pre", "compute", "d2h", "post")  # the reference Profiler's buckets, fft/fft_gpu.cu:17-57
+BATCH_MAX_DEVICES = 16
 
 _f32p = ctypes.POINTER(ctypes.c_float)
+
+
+class BatchDesc(ctypes.Structure):
+    """fdr_batch_desc of include/fdr.h"""
+    _fields_ = [("n_devices", ctypes.c_int), ("devices", ctypes.POINTER(ctypes.c_int)),
+                ("M", ctypes.c_int), ("N", ctypes.c_int), ("mode", ctypes.c_int), ("flags", ctypes.c_uint),
+                ("psf_host", ctypes.c_void_p), ("psf_rows", ctypes.c_int), ("psf_cols", ctypes.c_int), ("psf_stride", ctypes.c_int),
+                ("psf_size", ctypes.c_int), ("psf_angle_deg", ctypes.c_double), ("K", ctypes.c_float),
+                ("count", ctypes.c_int), ("rows", ctypes.c_int), ("cols", ctypes.c_int), ("stride", ctypes.c_int), ("out_stride", ctypes.c_int),
+                ("imgs_host", ctypes.POINTER(ctypes.c_void_p)), ("outs_host", ctypes.POINTER(ctypes.c_void_p)),
+                ("synth_seed", ctypes.c_uint64), ("steps", ctypes.c_int), ("warmup", ctypes.c_int),
+                ("nstreams", ctypes.c_int), ("group", ctypes.c_int), ("norm_area", ctypes.c_int)]
+
+
+class BatchStats(ctypes.Structure):
+    """fdr_batch_stats of include/fdr.h"""
+    _fields_ = [("n_devices", ctypes.c_int), ("first", ctypes.c_int * 16), ("images", ctypes.c_int * 16),
+                ("elapsed_ms", ctypes.c_double * 16), ("checksum", ctypes.c_double * 16), ("status", ctypes.c_int * 16),
+                ("wall_ms", ctypes.c_double), ("images_done", ctypes.c_longlong), ("mpixels_per_s", ctypes.c_double)]
 
 
 class FdrError(RuntimeError):
@@ -73,6 +90,10 @@ def _load():
     L.fdr_device_count.argtypes = [ctypes.POINTER(ci)]
     L.fdr_next_pow2.argtypes = [ci]
     L.fdr_is_pow2.argtypes = [ci]
+    L.fdr_optimal_dft_size.argtypes = [ci]
+    L.fdr_plan_set_option.argtypes = [vp, ci, ctypes.c_longlong]
+    L.fdr_plan_phase_times.argtypes = [vp, _f32p, ci]
+    L.fdr_batch_run.argtypes = [ctypes.POINTER(BatchDesc), ctypes.POINTER(BatchStats)]
     L.fdr_plan_create.argtypes = [ci, ci, ci, ci, cu, ctypes.POINTER(vp)]
     L.fdr_plan_destroy.argtypes = [vp]
     L.fdr_plan_dims.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
@@ -103,7 +124,8 @@ def _load():
                  "fdr_psf_motion", "fdr_psf_motion_dev", "fdr_set_psf", "fdr_set_psf_dev", "fdr_set_psf_motion",
                  "fdr_wiener_f32", "fdr_wiener_f32_dev", "fdr_wiener_batch_f32_dev", "fdr_wiener_batch_f32", "fdr_wiener_batch_ptrs_f32", "fdr_host_alloc", "fdr_host_free",
                  "fdr_white_balance_u8", "fdr_white_balance_u8_dev", "fdr_plan_set_concurrency", "fdr_plan_set_batching",
-                 "fdr_fft2d_c2c", "fdr_fft2d_c2c_dev", "fdr_fft1d_c2c", "fdr_dft_naive_c2c", "fdr_synth_image_dev", "fdr_plan_profile", "fdr_plan_pass_times"):
+                 "fdr_fft2d_c2c", "fdr_fft2d_c2c_dev", "fdr_fft1d_c2c", "fdr_dft_naive_c2c", "fdr_synth_image_dev", "fdr_plan_profile", "fdr_plan_pass_times",
+                 "fdr_optimal_dft_size", "fdr_plan_set_option", "fdr_plan_phase_times", "fdr_batch_run"):
         getattr(L, name).restype = ci
     return L
 
@@ -117,7 +139,7 @@ EXPORTED_SYMBOLS = (
     "fdr_host_alloc", "fdr_host_free", "fdr_white_balance_u8", "fdr_white_balance_u8_dev", "fdr_plan_set_concurrency",
     "fdr_plan_set_batching", "fdr_fft2d_c2c",
     "fdr_fft2d_c2c_dev", "fdr_fft1d_c2c", "fdr_dft_naive_c2c", "fdr_synth_image_dev", "fdr_plan_profile",
-    "fdr_plan_pass_times")
+    "fdr_plan_pass_times", "fdr_optimal_dft_size", "fdr_plan_set_option", "fdr_plan_phase_times", "fdr_batch_run")
 
 
 def _check(rc):
@@ -145,6 +167,11 @@ getNextPowerOf2 = nextPowerOfTwo  # utils.hpp:33-37
 def isPowerOfTwo(n):
     """utils.hpp:50-52"""
     return bool(lib.fdr_is_pow2(int(n)))
+
+
+def getOptimalDFTSize(n):
+    """cv::getOptimalDFTSize as fft/fft_serial.cpp:153-154 uses it: smallest 2^a 3^b 5^c >= n"""
+    return lib.fdr_optimal_dft_size(int(n))
 
 
 def motionBlurKernel(size, angle):
@@ -249,6 +276,15 @@ class Plan:
     def fft2d_dev(self, d_ptr, inverse=False, stream=None):
         _check(lib.fdr_fft2d_c2c_dev(self._h, ctypes.c_void_p(int(d_ptr)), int(inverse), _stream(stream)))
 
+    def set_option(self, option, value):
+        _check(lib.fdr_plan_set_option(self._h, int(option), int(value)))
+
+    def phase_times(self, reset=False):
+        """The reference Profiler's six buckets (ms) accumulated on this plan: dict alloc/h2d/pre/compute/d2h/post."""
+        ms = (ctypes.c_float * len(PHASES))()
+        _check(lib.fdr_plan_phase_times(self._h, ms, int(reset)))
+        return {k: float(ms[i]) for i, k in enumerate(PHASES)}
+
     # profiling
     def profile(self, enable=True):
         _check(lib.fdr_plan_profile(self._h, int(enable)))
@@ -308,11 +344,62 @@ def host_alloc(shape, dtype=np.float32):
 
 
 def wienerDeblur_myfft(img, psf, K, mode=MODE_PARITY, device=0, norm_area=NORM_PADDED):
-    """fft_gpu::wienerDeblur_myfft(img, psf, K): one channel, pads to powers of two on the device."""
+    """One channel the way the DRIVERS call the operator: pad to powers of two (serial.cpp:36 / fft_gpu.cu:287-288, on the
+    device), restore, normalise (default: over the padded area, serial.cpp:34-39), crop."""
     img = np.asarray(img, dtype=np.float32)
     with Plan(nextPowerOfTwo(img.shape[0]), nextPowerOfTwo(img.shape[1]), mode, device) as p:
         p.set_psf(psf, K)
         return p.wiener(img, norm_area)
+
+
+def wienerDeblur_myfft_unpadded(img, psf, K, mode=MODE_PARITY, device=0):
+    """fft_serial::wienerDeblur_myfft called DIRECTLY on a channel of any size (fft/fft_serial.cpp:141-261): pad to
+    getOptimalDFTSize (2^a 3^b 5^c; a non-power-of-two dimension is transformed by the naive DFT, :100-101), restore,
+    crop to the input size, normalise over the cropped plane (:243-246)."""
+    img = np.asarray(img, dtype=np.float32)
+    M, N = getOptimalDFTSize(img.shape[0]), getOptimalDFTSize(img.shape[1])
+    flags = 0 if (isPowerOfTwo(M) and isPowerOfTwo(N)) else FLAG_ANY_SIZE
+    with Plan(M, N, mode, device, flags=flags) as p:
+        p.set_psf(psf, K)
+        return p.wiener(img, NORM_CROPPED)
+
+
+def batch_run(devices, M, N, count, rows=None, cols=None, mode=MODE_FAST, flags=0, psf=None, psf_size=50, psf_angle=30.0, K=0.01,
+              imgs=None, seed=0x5EED0005, steps=1, warmup=0, nstreams=0, group=0, norm_area=NORM_PADDED):
+    """fdr_batch_run: `count` independent images sharded over `devices` (ordinals, may repeat) by the reference's
+    calculate_distribution rule, one host thread + plan per entry.  imgs = float32 [count, rows, cols] host array (results
+    returned) or None for the device-resident synthetic run.  Returns (stats dict, outputs or None)."""
+    rows = rows or M
+    cols = cols or N
+    d = BatchDesc()
+    devs = (ctypes.c_int * len(devices))(*[int(x) for x in devices])
+    d.n_devices, d.devices = len(devices), devs
+    d.M, d.N, d.mode, d.flags = int(M), int(N), int(mode), int(flags)
+    keep = []
+    if psf is not None:
+        psf = np.ascontiguousarray(psf, dtype=np.float32)
+        keep.append(psf)
+        d.psf_host, d.psf_rows, d.psf_cols, d.psf_stride = psf.ctypes.data, psf.shape[0], psf.shape[1], psf.shape[1]
+    d.psf_size, d.psf_angle_deg, d.K = int(psf_size), float(psf_angle), float(K)
+    d.count, d.rows, d.cols, d.stride, d.out_stride = int(count), int(rows), int(cols), int(cols), int(cols)
+    outs = None
+    if imgs is not None:
+        imgs = np.ascontiguousarray(imgs, dtype=np.float32)
+        assert imgs.shape == (count, rows, cols)
+        outs = np.empty_like(imgs)
+        pin = (ctypes.c_void_p * max(count, 1))(*[imgs[i].ctypes.data for i in range(count)])
+        pout = (ctypes.c_void_p * max(count, 1))(*[outs[i].ctypes.data for i in range(count)])
+        keep += [imgs, pin, pout]
+        d.imgs_host, d.outs_host = pin, pout
+    d.synth_seed, d.steps, d.warmup = int(seed), int(steps), int(warmup)
+    d.nstreams, d.group, d.norm_area = int(nstreams), int(group), int(norm_area)
+    st = BatchStats()
+    _check(lib.fdr_batch_run(ctypes.byref(d), ctypes.byref(st)))
+    n = st.n_devices
+    stats = {"first": list(st.first[:n]), "images": list(st.images[:n]), "elapsed_ms": list(st.elapsed_ms[:n]),
+             "checksum": list(st.checksum[:n]), "status": list(st.status[:n]), "wall_ms": st.wall_ms,
+             "images_done": st.images_done, "mpixels_per_s": st.mpixels_per_s}
+    return stats, outs
 
 
 def wienerDeblur_RGB_optimized(channels, psf, K, mode=MODE_PARITY, device=0, norm_area=NORM_PADDED):

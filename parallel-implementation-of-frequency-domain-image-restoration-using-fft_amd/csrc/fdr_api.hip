@@ -9,7 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace fdr;
@@ -67,6 +69,20 @@ void build_twiddles(int n, int mode, bool inverse, std::vector<float2>& out) {
     }
 }
 
+// n x n twiddle table of fft_serial::dft_naive_inplace (fft/fft_serial.cpp:71-87), forward direction, laid out
+// [t][k] so that adjacent threads (adjacent k) read adjacent entries: ang = 2.0f * CV_PI * k * t / n * sign evaluated left
+// to right in double, rounded to float, then the C library's cosf / sinf -- the calls the serial path makes.
+void build_naive_table(int n, std::vector<float2>& out) {
+    out.resize((size_t)n * n);
+    const double PI = 3.1415926535897932384626433832795;
+    for (int k = 0; k < n; ++k)
+        for (int t = 0; t < n; ++t) {
+            const float ang = (float)((double)2.0f * PI * (double)k * (double)t / (double)n * (double)-1.0f);
+            out[(size_t)t * n + k] = make_float2(cosf(ang), sinf(ang));
+        }
+}
+constexpr int kMaxNaiveLen = 4096;  // 128 MiB of table
+
 struct PassTimer {
     static constexpr int kMaxRecords = 8192;
     struct Rec { hipEvent_t a, b; int pass; };
@@ -106,8 +122,8 @@ struct fdr_plan {
     unsigned flags = 0;
     bool simple = false;
     int num_cu = 256;
-    int no_pipeline = 0;
-    int no_packing = 0;
+    bool generic = false;  // FDR_FLAG_ANY_SIZE with a non-power-of-two dimension: naive DFT along that dimension
+    float2 *naive_row = nullptr, *naive_col = nullptr;  // n x n tables of the non-power-of-two dimensions (length N / M)
     bool panel = false;
     size_t pstride = 0;  // panel stride (float2 elements)
     bool half = false;   // fast mode: only the non-redundant half of the Hermitian spectrum is kept (N/8 panels, Nyquist packed into column 0)
@@ -127,6 +143,10 @@ struct fdr_plan {
     float K = 0.f;
     bool have_psf = false;
     PassTimer timer;
+    // the reference Profiler's buckets (fdr_plan_phase_times): resolved sums + event pairs not read back yet
+    struct PhaseRec { hipEvent_t a, b; int phase; };
+    double phase_ms[FDR_N_PHASES] = {0, 0, 0, 0, 0, 0};
+    std::vector<PhaseRec> phase_pending;
     // batched mode: images alternate over `nslots` private workspaces, each on its own internal stream,
     // so the tail of one image's kernels overlaps the head of the next image's (slot 0 = the buffers above)
     struct Slot {
@@ -165,6 +185,30 @@ struct ScopedPass {
     }
 };
 
+// One hipEvent pair on stream s around a phase of the reference's Profiler (fft/fft_gpu.cu:17-57); read back by
+// resolve_phases.  Bounded: beyond 1024 unread pairs further phases go unrecorded until fdr_plan_phase_times is called.
+struct ScopedPhase {
+    fdr_plan* p; hipStream_t s; fdr_plan::PhaseRec rec; bool on;
+    ScopedPhase(fdr_plan* plan, int phase, hipStream_t st) : p(plan), s(st), on(false) {
+        if (p->phase_pending.size() < 1024) {
+            rec.a = p->timer.get(); rec.b = p->timer.get(); rec.phase = phase;
+            on = rec.a && rec.b;
+            if (on) (void)hipEventRecord(rec.a, s);
+        }
+    }
+    ~ScopedPhase() {
+        if (on) { (void)hipEventRecord(rec.b, s); p->phase_pending.push_back(rec); }
+    }
+};
+void resolve_phases(fdr_plan* p) {
+    for (auto& r : p->phase_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) p->phase_ms[r.phase] += ms;
+        p->timer.pool.push_back(r.a); p->timer.pool.push_back(r.b);
+    }
+    p->phase_pending.clear();
+}
+
 // names are static strings compared by pointer in PassTimer::pass_id
 const char* const kPassRowsFwd = "A rows: pad+FFT (real->complex)";
 const char* const kPassColsWiener = "B cols: FFT+Wiener";
@@ -194,10 +238,27 @@ int upload(float2** dst, const std::vector<float2>& v) {
 int dft2d_dev(fdr_plan* p, float2* d, float2* work2, bool inverse, hipStream_t s) {
     const float2* twr = inverse ? p->tw_row_i : p->tw_row_f;
     const float2* twc = inverse ? p->tw_col_i : p->tw_col_f;
-    if (p->simple) {
-        FDR_HIP(launch_simple_rows(d, p->M, p->N, p->logN, twr, p->mode, s));
+    if (p->simple) {  // the reference's own sequence: rows, transpose, rows, transpose (fft/fft_serial.cpp:113-139)
+        // one row pass over `rows` rows of length L held in `buf`, `tmp` free: radix-2 for powers of two, else the naive
+        // DFT (transform_row_inplace, :100-101), which runs out of place and is copied back
+        auto row_pass = [&](float2* buf, float2* tmp, int rows, int L, int logl, const float2* tw, const float2* naive) -> int {
+            if (naive) {
+                FDR_HIP(launch_dft_naive_rows(buf, tmp, rows, L, naive, inverse ? 1 : 0, s));
+                FDR_HIP(hipMemcpyAsync(buf, tmp, (size_t)rows * L * sizeof(float2), hipMemcpyDeviceToDevice, s));
+            } else if (p->generic && L >= 8) {  // register kernels, in place (parity arithmetic: direction-specific table)
+                RowArgs ra{};
+                ra.src_c = buf; ra.dst_c = buf; ra.M = rows;
+                FDR_HIP(launch_rows(logl, FDR_MODE_PARITY, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, inverse, ra, tw, s));
+            } else {
+                FDR_HIP(launch_simple_rows(buf, rows, L, logl, tw, p->mode, s));
+            }
+            return FDR_OK;
+        };
+        int rc = row_pass(d, work2, p->M, p->N, p->logN, twr, p->naive_row);
+        if (rc != FDR_OK) return rc;
         FDR_HIP(launch_transpose(d, work2, p->M, p->N, s));
-        FDR_HIP(launch_simple_rows(work2, p->N, p->M, p->logM, twc, p->mode, s));
+        rc = row_pass(work2, d, p->N, p->M, p->logM, twc, p->naive_col);
+        if (rc != FDR_OK) return rc;
         FDR_HIP(launch_transpose(work2, d, p->N, p->M, s));
         return FDR_OK;
     }
@@ -215,6 +276,7 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
     if (prows <= 0 || pcols <= 0 || pstride < pcols) return fail(FDR_ERR_ARG, "fdr_set_psf: bad PSF shape");
     if (prows > p->M || pcols > p->N)
         return fail(FDR_ERR_ARG, "fdr_set_psf: PSF larger than the padded image (copyMakeBorder would throw, fft_serial.cpp:168)");
+    ScopedPhase phase(p, FDR_PHASE_PRE, s);
     // pad top-left + forward 2-D FFT (fft/fft_serial.cpp:166-171,182)
     if (p->simple) {
         FDR_HIP(launch_pad_real_to_complex(d_psf, prows, pcols, pstride, p->filt, p->M, p->N, s));
@@ -223,7 +285,7 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
     } else if (p->panel) {
         RowArgs ra{};
         ra.src_real = d_psf; ra.src_rows = prows; ra.src_cols = pcols; ra.src_stride = pstride;
-        ra.dst_c = p->filt; ra.M = p->M; ra.no_packing = p->no_packing; ra.pstride = p->pstride; ra.half = p->half;
+        ra.dst_c = p->filt; ra.M = p->M; ra.pstride = p->pstride; ra.half = p->half;
         FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, ra, p->tw_row_f, s));
         ColArgs ca{};
         ca.data = p->filt; ca.N = p->N; ca.num_cu = p->num_cu; ca.pstride = p->pstride; ca.npanels = p->npanels;
@@ -275,16 +337,14 @@ int panel_stage_A(fdr_plan* p, fdr_plan::Slot& w, const float* d_img, int rows, 
     ScopedPass t(p, s, kPassRowsFwd);   // A: 4 rows per thread group, real -> panel-major (half) spectrum
     RowArgs a{};
     a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
-    a.dst_c = w.work; a.M = p->M; a.no_packing = p->no_packing; a.pstride = p->pstride; a.half = p->half;
+    a.dst_c = w.work; a.M = p->M; a.pstride = p->pstride; a.half = p->half;
     FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
     return FDR_OK;
 }
 int panel_stage_B(fdr_plan* p, fdr_plan::Slot* const* ws, int n, hipStream_t s) {
-    ScopedPass t(p, s, kPassColsFusedN[n]);  // B': per panel, columns forward * W * inverse, persistent + double-buffered
+    ScopedPass t(p, s, kPassColsFusedN[n]);  // B': per panel, columns forward * W * inverse
     ColArgs c{};
-    c.data = ws[0]->work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu; c.no_pipeline = p->no_pipeline;
-    c.lean = (p->flags & FDR_FLAG_LEAN_COLS) != 0;
-    c.v16 = (p->flags & (FDR_FLAG_COLS8 | FDR_FLAG_LEAN_COLS | FDR_FLAG_NO_PIPELINE)) == 0;  // default from 1024-point columns up
+    c.data = ws[0]->work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu;
     c.pstride = p->pstride; c.npanels = p->npanels; c.packed0 = p->half ? 1 : 0;
     c.batch.nimg = n;
 #ifdef FDR_DEBUG_STAMPS
@@ -328,7 +388,7 @@ int panel_stage_CE(fdr_plan* p, fdr_plan::Slot& w, int rows, int cols, float* d_
         ScopedPass t(p, s, kPassRowsInvReal);
         RowArgs a{};
         a.src_c = w.work; a.dst_real = w.raw; a.mm_part = w.mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
-        a.no_packing = p->no_packing; a.pstride = p->pstride; a.half = p->half;
+        a.pstride = p->pstride; a.half = p->half;
         FDR_HIP(launch_rows4(p->logN, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, a, p->tw_row_f, s));
     }
     {   // E: normalise to [0,1] and crop
@@ -341,13 +401,13 @@ int panel_stage_CE(fdr_plan* p, fdr_plan::Slot& w, int rows, int cols, float* d_
 }
 
 // the same passes for a GROUP of 2..4 images in one launch each (blockIdx.y = image); packed half-spectrum path only
-bool can_batch_rows(const fdr_plan* p) { return p->half && !p->no_packing && !p->fused_norm; }
+bool can_batch_rows(const fdr_plan* p) { return p->half && !p->fused_norm; }
 int panel_stage_A_batch(fdr_plan* p, fdr_plan::Slot* const* ws, int n, const float* const* d_imgs, int rows, int cols, int stride,
                         hipStream_t s) {
     ScopedPass t(p, s, kPassRowsFwdN[n]);
     RowArgs a{};
     a.src_real = d_imgs[0]; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
-    a.dst_c = ws[0]->work; a.M = p->M; a.no_packing = 0; a.pstride = p->pstride; a.half = 1;
+    a.dst_c = ws[0]->work; a.M = p->M; a.pstride = p->pstride; a.half = 1;
     a.batch.nimg = n;
     for (int k = 0; k < 4; ++k) { a.batch.src_real[k] = d_imgs[k < n ? k : 0]; a.batch.spec[k] = ws[k < n ? k : 0]->work; }
     FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
@@ -359,7 +419,7 @@ int panel_stage_CE_batch(fdr_plan* p, fdr_plan::Slot* const* ws, int n, int rows
         ScopedPass t(p, s, kPassRowsInvRealN[n]);
         RowArgs a{};
         a.src_c = ws[0]->work; a.dst_real = ws[0]->raw; a.mm_part = ws[0]->mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
-        a.no_packing = 0; a.pstride = p->pstride; a.half = 1;
+        a.pstride = p->pstride; a.half = 1;
         a.batch.nimg = n;
         for (int k = 0; k < 4; ++k) {
             const fdr_plan::Slot* w = ws[k < n ? k : 0];
@@ -435,33 +495,12 @@ int wiener_dev_impl(fdr_plan* p, fdr_plan::Slot& w, const float* d_img, int rows
             FDR_HIP(launch_cols(p->logM, p->mode, COL_INV_REAL, c, p->tw_col_f, p->tw_col_i, s));
             n_part = cols_minmax_partials(p->logM, p->N);
         }
-    } else if (p->panel) {
+    } else {  // fast mode runs on the panel path (or the simple path for dimensions below 8)
         fdr_plan::Slot* one[1] = {&w};
         int rc = panel_stage_A(p, w, d_img, rows, cols, stride, s);
         if (rc == FDR_OK) rc = panel_stage_B(p, one, 1, s);
         if (rc == FDR_OK) rc = panel_stage_CE(p, w, rows, cols, d_out, out_stride, mm_rows, mm_cols, s);
         return rc;
-    } else {
-        {   // A
-            ScopedPass t(p, s, kPassRowsFwd);
-            RowArgs a{};
-            a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
-            a.dst_c = w.work; a.M = p->M;
-            FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_REAL, ROW_OUT_COMPLEX, false, a, p->tw_row_f, s));
-        }
-        {   // B': columns forward, multiply by W, columns inverse -- one HBM round trip
-            ScopedPass t(p, s, kPassColsFused);
-            ColArgs c{};
-            c.data = w.work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu; c.no_pipeline = p->no_pipeline;
-            FDR_HIP(launch_cols(p->logM, p->mode, COL_FUSED, c, p->tw_col_f, p->tw_col_i, s));
-        }
-        {   // C': rows inverse, real plane, min/max
-            ScopedPass t(p, s, kPassRowsInvReal);
-            RowArgs a{};
-            a.src_c = w.work; a.dst_real = w.raw; a.mm_part = w.mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
-            FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, true, a, p->tw_row_f, s));
-            n_part = rows_minmax_partials(p->logN, p->M);
-        }
     }
     {   // E: normalise to [0,1] and crop (fft/fft_serial.cpp:246, serial.cpp:38)
         ScopedPass t(p, s, kPassNormalize);
@@ -500,69 +539,102 @@ int fdr_device_count(int* count) {
 int fdr_next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }  // utils.hpp:27-37
 int fdr_is_pow2(int n) { return n > 0 && ((n & (n - 1)) == 0); }           // utils.hpp:50-52
 
-int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan** out) {
-    if (!out) return fail(FDR_ERR_ARG, "fdr_plan_create: null out");
-    *out = nullptr;
-    if (M <= 0 || N <= 0) return fail(FDR_ERR_ARG, "fdr_plan_create: non-positive dimension");
-    if (!fdr_is_pow2(M) || !fdr_is_pow2(N))
-        return fail(FDR_ERR_NOT_POW2, "fdr_plan_create: M and N must be powers of two (pad first, utils.hpp:40-47)");
-    if (M > 8192 || N > 8192) return fail(FDR_ERR_ARG, "fdr_plan_create: dimension above 8192 (one row must fit LDS)");
-    if (mode != FDR_MODE_PARITY && mode != FDR_MODE_FAST) return fail(FDR_ERR_ARG, "fdr_plan_create: unknown mode");
-    FDR_HIP(hipSetDevice(device));
-    fdr_plan* p = new (std::nothrow) fdr_plan();
-    if (!p) return fail(FDR_ERR_ALLOC, "fdr_plan_create: out of host memory");
-    p->device = device; p->M = M; p->N = N; p->logM = ilog2(M); p->logN = ilog2(N); p->mode = mode; p->flags = flags;
-    p->simple = (flags & FDR_FLAG_SIMPLE_PATH) != 0 || M < 8 || N < 8;
-    p->no_pipeline = (flags & FDR_FLAG_NO_PIPELINE) != 0;
-    p->no_packing = (flags & FDR_FLAG_NO_PACKING) != 0;
-    p->panel = mode == FDR_MODE_FAST && !p->simple && (flags & FDR_FLAG_ROWMAJOR) == 0;
+// cv::getOptimalDFTSize as the serial path uses it (fft/fft_serial.cpp:153-154): smallest 2^a 3^b 5^c >= n
+int fdr_optimal_dft_size(int n) {
+    if (n <= 1) return n < 0 ? -1 : 1;
+    for (long long best = -1, p2 = 1; p2 < 2LL * n; p2 *= 2) {
+        for (long long p3 = p2; p3 < 2LL * n; p3 *= 3)
+            for (long long p5 = p3; p5 < 2LL * n; p5 *= 5)
+                if (p5 >= n && (best < 0 || p5 < best)) best = p5;
+        if (p2 * 2 >= 2LL * n) return (int)best;
+    }
+    return -1;
+}
+
+static int plan_create_impl(fdr_plan* p, int device, int M, int N, int mode, unsigned flags) {
+    p->device = device; p->M = M; p->N = N; p->mode = mode; p->flags = flags;
+    const bool pow2 = fdr_is_pow2(M) && fdr_is_pow2(N);
+    p->generic = !pow2;  // only reachable with FDR_FLAG_ANY_SIZE: reference-shaped passes, parity arithmetic
+    if (p->generic) p->mode = mode = FDR_MODE_PARITY;
+    p->logM = fdr_is_pow2(M) ? ilog2(M) : -1;
+    p->logN = fdr_is_pow2(N) ? ilog2(N) : -1;
+    p->simple = p->generic || (flags & FDR_FLAG_SIMPLE_PATH) != 0 || M < 8 || N < 8;
+    p->panel = mode == FDR_MODE_FAST && !p->simple;
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) p->num_cu = cus;
     }
     size_t P = (size_t)M * N;
-    if (p->panel) {  // panel-major buffers: N/4 panels of PS elements
-        p->pstride = (size_t)M * 4 + ((flags & FDR_FLAG_POW2_PANELS) ? 0 : 16);
-        p->half = !p->no_packing && N >= 32 && (flags & FDR_FLAG_FULL_SPECTRUM) == 0;
+    if (p->panel) {  // panel-major buffers: panels of 4 columns, PS elements apart (not a power of two: channel skew)
+        p->pstride = (size_t)M * 4 + 16;
+        p->half = N >= 32 && (flags & FDR_FLAG_FULL_SPECTRUM) == 0;
         p->npanels = p->half ? N / 8 : N / 4;
         P = (size_t)p->npanels * p->pstride;
         p->fused_norm = p->half && (flags & FDR_FLAG_FUSED_NORM) != 0 &&
                         rows4_fused_geometry(p->logN, M, p->num_cu, &p->fused_R, &p->fused_nwg) != 0;
-        if (const char* e = getenv("FDR_DEBUG_SPIN_LIMIT")) p->spin_limit = (unsigned)strtoul(e, nullptr, 10);  // tests: force the fallback
     }
     std::vector<float2> t;
     int rc = FDR_OK;
-    build_twiddles(N, mode, false, t); if ((rc = upload(&p->tw_row_f, t)) != FDR_OK) goto bad;
-    build_twiddles(N, mode, true, t);  if ((rc = upload(&p->tw_row_i, t)) != FDR_OK) goto bad;
-    build_twiddles(M, mode, false, t); if ((rc = upload(&p->tw_col_f, t)) != FDR_OK) goto bad;
-    build_twiddles(M, mode, true, t);  if ((rc = upload(&p->tw_col_i, t)) != FDR_OK) goto bad;
+    if (fdr_is_pow2(N)) {
+        build_twiddles(N, mode, false, t); if ((rc = upload(&p->tw_row_f, t)) != FDR_OK) return rc;
+        build_twiddles(N, mode, true, t);  if ((rc = upload(&p->tw_row_i, t)) != FDR_OK) return rc;
+    } else {
+        build_naive_table(N, t); if ((rc = upload(&p->naive_row, t)) != FDR_OK) return rc;
+    }
+    if (fdr_is_pow2(M)) {
+        build_twiddles(M, mode, false, t); if ((rc = upload(&p->tw_col_f, t)) != FDR_OK) return rc;
+        build_twiddles(M, mode, true, t);  if ((rc = upload(&p->tw_col_i, t)) != FDR_OK) return rc;
+    } else if (M == N) {
+        p->naive_col = p->naive_row;
+    } else {
+        build_naive_table(M, t); if ((rc = upload(&p->naive_col, t)) != FDR_OK) return rc;
+    }
     if (hipMalloc((void**)&p->work, P * sizeof(float2)) != hipSuccess ||
         hipMalloc((void**)&p->filt, P * sizeof(float2)) != hipSuccess ||
         hipMalloc((void**)&p->raw, (size_t)M * N * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&p->mm, 2 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&p->mm_part, (size_t)(p->mm_part_cap = (int)(((size_t)N + 255) / 256 * M + 8192)) * sizeof(float2)) != hipSuccess ||
-        (p->simple && hipMalloc((void**)&p->work2, P * sizeof(float2)) != hipSuccess)) {
-        rc = fail(FDR_ERR_ALLOC, "fdr_plan_create: hipMalloc of the plan workspace failed");
-        goto bad;
-    }
-    if (p->fused_norm && hipEventCreateWithFlags(&p->fused_done, hipEventDisableTiming) != hipSuccess) {
-        rc = fail(FDR_ERR_HIP, "fdr_plan_create: hipEventCreate failed");
-        goto bad;
-    }
+        (p->simple && hipMalloc((void**)&p->work2, P * sizeof(float2)) != hipSuccess))
+        return fail(FDR_ERR_ALLOC, "fdr_plan_create: hipMalloc of the plan workspace failed");
+    if (p->fused_norm && hipEventCreateWithFlags(&p->fused_done, hipEventDisableTiming) != hipSuccess)
+        return fail(FDR_ERR_HIP, "fdr_plan_create: hipEventCreate failed");
     p->ws_elems = P;
     p->slots[0].work = p->work; p->slots[0].work2 = p->work2; p->slots[0].raw = p->raw; p->slots[0].mm = p->mm;
     p->slots[0].mm_part = p->mm_part;
+    return FDR_OK;
+}
+
+int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan** out) {
+    if (!out) return fail(FDR_ERR_ARG, "fdr_plan_create: null out");
+    *out = nullptr;
+    if (M <= 0 || N <= 0) return fail(FDR_ERR_ARG, "fdr_plan_create: non-positive dimension");
+    if (mode != FDR_MODE_PARITY && mode != FDR_MODE_FAST) return fail(FDR_ERR_ARG, "fdr_plan_create: unknown mode");
+    if (!fdr_is_pow2(M) || !fdr_is_pow2(N)) {
+        if ((flags & FDR_FLAG_ANY_SIZE) == 0)
+            return fail(FDR_ERR_NOT_POW2, "fdr_plan_create: M and N must be powers of two (pad first, utils.hpp:40-47) unless FDR_FLAG_ANY_SIZE is set");
+        if ((!fdr_is_pow2(M) && M > kMaxNaiveLen) || (!fdr_is_pow2(N) && N > kMaxNaiveLen))
+            return fail(FDR_ERR_ARG, "fdr_plan_create: non-power-of-two dimension above 4096 (naive-DFT twiddle table)");
+    }
+    if (M > 8192 || N > 8192) return fail(FDR_ERR_ARG, "fdr_plan_create: dimension above 8192 (one row must fit LDS)");
+    FDR_HIP(hipSetDevice(device));
+    const auto t0 = std::chrono::steady_clock::now();
+    fdr_plan* p = new (std::nothrow) fdr_plan();
+    if (!p) return fail(FDR_ERR_ALLOC, "fdr_plan_create: out of host memory");
+    const int rc = plan_create_impl(p, device, M, N, mode, flags);
+    if (rc != FDR_OK) {
+        const std::string msg = g_last_error;  // fdr_plan_destroy does not touch it, but keep the first failure's text
+        fdr_plan_destroy(p);
+        g_last_error = msg;
+        return rc;
+    }
+    p->phase_ms[FDR_PHASE_ALLOC] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *out = p;
     return FDR_OK;
-bad:
-    fdr_plan_destroy(p);
-    return rc;
 }
 
 int fdr_plan_destroy(fdr_plan* p) {
     if (!p) return FDR_OK;
     (void)hipSetDevice(p->device);
-    p->timer.destroy();
     for (int k = 1; k < fdr_plan::kMaxSlots; ++k) {
         fdr_plan::Slot& w = p->slots[k];
         (void)hipFree(w.work); (void)hipFree(w.work2); (void)hipFree(w.raw); (void)hipFree(w.mm); (void)hipFree(w.mm_part);
@@ -575,6 +647,11 @@ int fdr_plan_destroy(fdr_plan* p) {
     if (p->fork) (void)hipEventDestroy(p->fork);
     if (p->fused_done) (void)hipEventDestroy(p->fused_done);
     (void)hipFree(p->tw_row_f); (void)hipFree(p->tw_row_i); (void)hipFree(p->tw_col_f); (void)hipFree(p->tw_col_i);
+    if (p->naive_col != p->naive_row) (void)hipFree(p->naive_col);
+    (void)hipFree(p->naive_row);
+    for (auto& r : p->phase_pending) { p->timer.pool.push_back(r.a); p->timer.pool.push_back(r.b); }
+    p->phase_pending.clear();
+    p->timer.destroy();
     (void)hipFree(p->work); (void)hipFree(p->work2); (void)hipFree(p->filt); (void)hipFree(p->raw);
     (void)hipFree(p->psf_dev); (void)hipFree(p->mm); (void)hipFree(p->mm_part);
     (void)hipFree(p->stage_in); (void)hipFree(p->stage_out);
@@ -587,6 +664,28 @@ int fdr_plan_dims(const fdr_plan* p, int* M, int* N, int* mode) {
     if (M) *M = p->M;
     if (N) *N = p->N;
     if (mode) *mode = p->mode;
+    return FDR_OK;
+}
+
+int fdr_plan_set_option(fdr_plan* p, int option, long long value) {
+    if (!p) return fail(FDR_ERR_ARG, "fdr_plan_set_option: null plan");
+    switch (option) {
+        case FDR_OPT_FUSED_SPIN_LIMIT:
+            if (value < 0 || value > 0xffffffffLL) return fail(FDR_ERR_ARG, "fdr_plan_set_option: spin limit out of range");
+            p->spin_limit = (unsigned)value;
+            return FDR_OK;
+        default:
+            return fail(FDR_ERR_ARG, "fdr_plan_set_option: unknown option");
+    }
+}
+
+int fdr_plan_phase_times(fdr_plan* p, float ms[FDR_N_PHASES], int reset) {
+    if (!p || !ms) return fail(FDR_ERR_ARG, "fdr_plan_phase_times: null argument");
+    FDR_HIP(hipSetDevice(p->device));
+    resolve_phases(p);
+    for (int i = 0; i < FDR_N_PHASES; ++i) ms[i] = (float)p->phase_ms[i];
+    if (reset)
+        for (int i = 0; i < FDR_N_PHASES; ++i) p->phase_ms[i] = 0.0;
     return FDR_OK;
 }
 
@@ -621,11 +720,15 @@ int fdr_set_psf(fdr_plan* p, const float* psf_host, int prows, int pcols, int ps
     FDR_HIP(hipSetDevice(p->device));
     int rc = ensure_psf_staging(p, (size_t)prows * pcols);
     if (rc != FDR_OK) return rc;
-    FDR_HIP(hipMemcpy2D(p->psf_dev, (size_t)pcols * sizeof(float), psf_host, (size_t)pstride * sizeof(float),
-                        (size_t)pcols * sizeof(float), prows, hipMemcpyHostToDevice));
+    {
+        ScopedPhase ph(p, FDR_PHASE_H2D, nullptr);
+        FDR_HIP(hipMemcpy2D(p->psf_dev, (size_t)pcols * sizeof(float), psf_host, (size_t)pstride * sizeof(float),
+                            (size_t)pcols * sizeof(float), prows, hipMemcpyHostToDevice));
+    }
     rc = set_psf_dev_impl(p, p->psf_dev, prows, pcols, pcols, K, nullptr);
     if (rc != FDR_OK) return rc;
     FDR_HIP(hipStreamSynchronize(nullptr));
+    resolve_phases(p);
     return FDR_OK;
 }
 
@@ -664,7 +767,7 @@ int fdr_wiener_batch_f32_dev(fdr_plan* p, const float* d_imgs, size_t img_pitch,
         for (int k = 0; k < ns; ++k) FDR_HIP(hipStreamWaitEvent(p->slots[k * group].stream, p->fork, 0));
     }
     int chunk = 0;
-    for (int i0 = 0; i0 < count; i0 += group, ++chunk) {
+    for (int i0 = 0; i0 < count && rc == FDR_OK; i0 += group, ++chunk) {
         const int n = count - i0 < group ? count - i0 : group;
         const int sidx = chunk % ns;
         fdr_plan::Slot* ws[fdr_plan::kMaxSlots];
@@ -673,7 +776,6 @@ int fdr_wiener_batch_f32_dev(fdr_plan* p, const float* d_imgs, size_t img_pitch,
         if (!p->panel) {
             rc = wiener_dev_impl(p, *ws[0], d_imgs + (size_t)i0 * img_pitch, rows, cols, stride, d_out + (size_t)i0 * out_pitch,
                                  out_stride, norm_area, s);
-            if (rc != FDR_OK) return rc;
             continue;
         }
         if (n > 1 && can_batch_rows(p)) {  // every pass once for the whole group
@@ -682,7 +784,6 @@ int fdr_wiener_batch_f32_dev(fdr_plan* p, const float* d_imgs, size_t img_pitch,
             rc = panel_stage_A_batch(p, ws, n, ins, rows, cols, stride, s);
             if (rc == FDR_OK) rc = panel_stage_B(p, ws, n, s);
             if (rc == FDR_OK) rc = panel_stage_CE_batch(p, ws, n, rows, cols, outs, out_stride, mm_rows, mm_cols, s);
-            if (rc != FDR_OK) return rc;
             continue;
         }
         for (int k = 0; k < n && rc == FDR_OK; ++k)
@@ -690,15 +791,21 @@ int fdr_wiener_batch_f32_dev(fdr_plan* p, const float* d_imgs, size_t img_pitch,
         if (rc == FDR_OK) rc = panel_stage_B(p, ws, n, s);
         for (int k = 0; k < n && rc == FDR_OK; ++k)
             rc = panel_stage_CE(p, *ws[k], rows, cols, d_out + (size_t)(i0 + k) * out_pitch, out_stride, mm_rows, mm_cols, s);
-        if (rc != FDR_OK) return rc;
     }
-    if (ns > 1) {  // join: the caller's stream continues after every internal stream has drained
+    if (ns > 1) {  // join -- also after an error: the caller's stream continues only after every internal stream has
+                   // drained, so work already queued there cannot still be writing d_out when the caller goes on
+        const std::string first_error = g_last_error;
         for (int k = 0; k < ns; ++k) {
-            FDR_HIP(hipEventRecord(p->slots[k * group].done, p->slots[k * group].stream));
-            FDR_HIP(hipStreamWaitEvent(us, p->slots[k * group].done, 0));
+            hipError_t e = hipEventRecord(p->slots[k * group].done, p->slots[k * group].stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(us, p->slots[k * group].done, 0);
+            if (e != hipSuccess) {  // cannot order the streams: drain them on the host instead
+                (void)hipStreamSynchronize(p->slots[k * group].stream);
+                if (rc == FDR_OK) rc = fail(FDR_ERR_HIP, std::string("fdr_wiener_batch_f32_dev: join failed: ") + hipGetErrorString(e));
+            }
         }
+        if (rc != FDR_OK && !first_error.empty() && first_error != g_last_error && rc != FDR_ERR_HIP) g_last_error = first_error;
     }
-    return FDR_OK;
+    return rc;
 }
 
 int fdr_plan_set_batching(fdr_plan* p, int nstreams, int group) {
@@ -748,13 +855,23 @@ int fdr_wiener_f32(fdr_plan* p, const float* img_host, int rows, int cols, int s
         p->stage_cap = cap;
     }
     float *d_in = p->stage_in, *d_out = p->stage_out;
-    hipError_t e = hipMemcpy2D(d_in, (size_t)cols * sizeof(float), img_host, (size_t)stride * sizeof(float),
-                               (size_t)cols * sizeof(float), rows, hipMemcpyHostToDevice);
+    hipError_t e;
+    {
+        ScopedPhase ph(p, FDR_PHASE_H2D, nullptr);
+        e = hipMemcpy2D(d_in, (size_t)cols * sizeof(float), img_host, (size_t)stride * sizeof(float),
+                        (size_t)cols * sizeof(float), rows, hipMemcpyHostToDevice);
+    }
     int rc = FDR_OK;
-    if (e == hipSuccess) rc = wiener_dev_impl(p, p->slots[0], d_in, rows, cols, cols, d_out, cols, norm_area, nullptr);
-    if (e == hipSuccess && rc == FDR_OK)
+    if (e == hipSuccess) {
+        ScopedPhase ph(p, FDR_PHASE_COMPUTE, nullptr);
+        rc = wiener_dev_impl(p, p->slots[0], d_in, rows, cols, cols, d_out, cols, norm_area, nullptr);
+    }
+    if (e == hipSuccess && rc == FDR_OK) {
+        ScopedPhase ph(p, FDR_PHASE_D2H, nullptr);
         e = hipMemcpy2D(out_host, (size_t)out_stride * sizeof(float), d_out, (size_t)cols * sizeof(float),
                         (size_t)cols * sizeof(float), rows, hipMemcpyDeviceToHost);
+    }
+    if (e == hipSuccess) resolve_phases(p);
     if (rc != FDR_OK) return rc;
     FDR_HIP(e);
     return FDR_OK;
@@ -823,21 +940,29 @@ int fdr_wiener_batch_ptrs_f32(fdr_plan* p, const float* const* imgs_host, float*
             float* dst = outs_host[i];
             // slot k is free again once image i-D has left the device (its D2H read d_out[k], its kernels read d_in[k])
             if (i >= D && bad(hipStreamWaitEvent(s_in, e_out[k], 0))) break;
-            if (bad(hipMemcpy2DAsync(d_in[k], rowb, src, (size_t)stride * sizeof(float), rowb, rows, hipMemcpyHostToDevice, s_in)) ||
-                bad(hipEventRecord(e_in[k], s_in)) || bad(hipStreamWaitEvent(s_cmp, e_in[k], 0)))
-                break;
-            rc = wiener_dev_impl(p, p->slots[0], d_in[k], rows, cols, cols, d_out[k], cols, norm_area, s_cmp);
+            {
+                ScopedPhase ph(p, FDR_PHASE_H2D, s_in);
+                if (bad(hipMemcpy2DAsync(d_in[k], rowb, src, (size_t)stride * sizeof(float), rowb, rows, hipMemcpyHostToDevice, s_in))) break;
+            }
+            if (bad(hipEventRecord(e_in[k], s_in)) || bad(hipStreamWaitEvent(s_cmp, e_in[k], 0))) break;
+            {
+                ScopedPhase ph(p, FDR_PHASE_COMPUTE, s_cmp);
+                rc = wiener_dev_impl(p, p->slots[0], d_in[k], rows, cols, cols, d_out[k], cols, norm_area, s_cmp);
+            }
             if (rc != FDR_OK) break;
-            if (bad(hipEventRecord(e_cmp[k], s_cmp)) || bad(hipStreamWaitEvent(s_out, e_cmp[k], 0)) ||
-                bad(hipMemcpy2DAsync(dst, (size_t)out_stride * sizeof(float), d_out[k], rowb, rowb, rows, hipMemcpyDeviceToHost, s_out)) ||
-                bad(hipEventRecord(e_out[k], s_out)))
-                break;
+            if (bad(hipEventRecord(e_cmp[k], s_cmp)) || bad(hipStreamWaitEvent(s_out, e_cmp[k], 0))) break;
+            {
+                ScopedPhase ph(p, FDR_PHASE_D2H, s_out);
+                if (bad(hipMemcpy2DAsync(dst, (size_t)out_stride * sizeof(float), d_out[k], rowb, rowb, rows, hipMemcpyDeviceToHost, s_out))) break;
+            }
+            if (bad(hipEventRecord(e_out[k], s_out))) break;
         }
     } while (false);
     // everything queued must have left the device before the buffers go (also on the error paths)
     if (s_in) (void)hipStreamSynchronize(s_in);
     if (s_cmp) (void)hipStreamSynchronize(s_cmp);
     if (s_out) { hipError_t es = hipStreamSynchronize(s_out); if (e == hipSuccess) e = es; }
+    resolve_phases(p);  // the event pairs live in the plan's pool, the streams they were recorded on go away below
     for (int k = 0; k < D; ++k) {
         (void)hipFree(d_in[k]); (void)hipFree(d_out[k]);
         if (e_in[k]) (void)hipEventDestroy(e_in[k]);
@@ -880,14 +1005,22 @@ int fdr_fft2d_c2c(fdr_plan* p, float* data_host, int inverse) {
 int fdr_dft_naive_c2c(float* data_host, int n, int inverse) {
     if (!data_host || n < 0) return fail(FDR_ERR_ARG, "fdr_dft_naive_c2c: bad argument");
     if (n <= 1) return FDR_OK;  // fft/fft_serial.cpp:74
-    float2 *a = nullptr, *b = nullptr;
+    float2 *a = nullptr, *b = nullptr, *tab = nullptr;
     const size_t bytes = (size_t)n * sizeof(float2);
     FDR_HIP(hipMalloc((void**)&a, bytes));
     if (hipMalloc((void**)&b, bytes) != hipSuccess) { (void)hipFree(a); return fail(FDR_ERR_ALLOC, "fdr_dft_naive_c2c: hipMalloc"); }
     hipError_t e = hipMemcpy(a, data_host, bytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = launch_dft_naive(a, b, n, inverse, nullptr);
+    if (n <= kMaxNaiveLen) {  // host-generated twiddles: the bits of the serial path's cosf / sinf
+        std::vector<float2> t;
+        build_naive_table(n, t);
+        if (e == hipSuccess) e = hipMalloc((void**)&tab, t.size() * sizeof(float2));
+        if (e == hipSuccess) e = hipMemcpy(tab, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = launch_dft_naive_rows(a, b, 1, n, tab, inverse, nullptr);
+    } else if (e == hipSuccess) {
+        e = launch_dft_naive(a, b, n, inverse, nullptr);
+    }
     if (e == hipSuccess) e = hipMemcpy(data_host, b, bytes, hipMemcpyDeviceToHost);
-    (void)hipFree(a); (void)hipFree(b);
+    (void)hipFree(a); (void)hipFree(b); (void)hipFree(tab);
     FDR_HIP(e);
     return FDR_OK;
 }
@@ -976,6 +1109,163 @@ int fdr_synth_image_dev(int device, uint64_t seed, uint64_t first_index, size_t 
     if (!d_out && count) return fail(FDR_ERR_ARG, "fdr_synth_image_dev: null output");
     FDR_HIP(hipSetDevice(device));
     FDR_HIP(launch_synth(seed, first_index, count, d_out, (hipStream_t)stream));
+    return FDR_OK;
+}
+
+// ---- multi-GPU batched mode for C / C++ callers: one host thread, one plan, one PSF spectrum per device entry ----
+namespace {
+
+struct BatchWorker {
+    int index = 0, device = 0, first = 0, count = 0;
+    int status = FDR_OK;
+    std::string error;
+    double elapsed_ms = 0.0, checksum = 0.0;
+    std::chrono::steady_clock::time_point t_end;
+};
+
+// deterministic checksum of `count` floats on the device: per-block partial sums in double, folded on the host
+__global__ void checksum_kernel(const float* __restrict__ x, size_t count, double* __restrict__ part) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) acc += (double)x[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+int batch_worker_run(const fdr_batch_desc* d, BatchWorker* w, std::chrono::steady_clock::time_point* t_start_out) {
+    fdr_plan* plan = nullptr;
+    float *d_in = nullptr, *d_out = nullptr;
+    double* d_part = nullptr;
+    hipStream_t stream = nullptr;
+    int rc = FDR_OK;
+    auto body = [&]() -> int {
+        if (w->count == 0) return FDR_OK;
+        int r = fdr_plan_create(w->device, d->M, d->N, d->mode, d->flags, &plan);
+        if (r != FDR_OK) return r;
+        if (d->psf_host) r = fdr_set_psf(plan, d->psf_host, d->psf_rows, d->psf_cols, d->psf_stride, d->K);
+        else r = fdr_set_psf_motion(plan, d->psf_size, d->psf_angle_deg, d->K, nullptr);
+        if (r != FDR_OK) return r;
+        if (d->imgs_host) {  // host images: the pipelined host batch over this worker's shard
+            const auto t0 = std::chrono::steady_clock::now();
+            *t_start_out = t0;
+            r = fdr_wiener_batch_ptrs_f32(plan, d->imgs_host + w->first, d->outs_host + w->first, w->count, d->rows, d->cols, d->stride,
+                                          d->out_stride, d->norm_area);
+            w->t_end = std::chrono::steady_clock::now();
+            w->elapsed_ms = std::chrono::duration<double, std::milli>(w->t_end - t0).count();
+            if (r != FDR_OK) return r;
+            double acc = 0.0;
+            for (int i = 0; i < w->count; ++i)
+                for (int y = 0; y < d->rows; ++y) {
+                    const float* row = d->outs_host[w->first + i] + (size_t)y * d->out_stride;
+                    for (int x = 0; x < d->cols; ++x) acc += (double)row[x];
+                }
+            w->checksum = acc;
+            return FDR_OK;
+        }
+        // synthetic, device resident
+        const int ns = d->nstreams > 0 ? d->nstreams : (d->M * (size_t)d->N <= (size_t)2048 * 2048 ? 2 : 3);
+        const int gr = d->group > 0 ? d->group : (d->M * (size_t)d->N <= (size_t)2048 * 2048 ? 4 : 1);
+        r = fdr_plan_set_batching(plan, ns, d->mode == FDR_MODE_FAST ? gr : 1);
+        if (r != FDR_OK) return r;
+        const size_t P = (size_t)d->rows * d->cols, total = P * (size_t)w->count;
+        FDR_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        FDR_HIP(hipMalloc((void**)&d_in, total * sizeof(float)));
+        FDR_HIP(hipMalloc((void**)&d_out, total * sizeof(float)));
+        FDR_HIP(hipMalloc((void**)&d_part, 1024 * sizeof(double)));
+        FDR_HIP(launch_synth(d->synth_seed, (uint64_t)w->first * P, total, d_in, stream));
+        for (int k = 0; k < d->warmup && r == FDR_OK; ++k)
+            r = fdr_wiener_batch_f32_dev(plan, d_in, P, w->count, d->rows, d->cols, d->cols, d_out, P, d->cols, d->norm_area, stream);
+        FDR_HIP(hipStreamSynchronize(stream));
+        if (r != FDR_OK) return r;
+        const auto t0 = std::chrono::steady_clock::now();
+        *t_start_out = t0;
+        for (int k = 0; k < d->steps && r == FDR_OK; ++k)
+            r = fdr_wiener_batch_f32_dev(plan, d_in, P, w->count, d->rows, d->cols, d->cols, d_out, P, d->cols, d->norm_area, stream);
+        FDR_HIP(hipStreamSynchronize(stream));
+        w->t_end = std::chrono::steady_clock::now();
+        w->elapsed_ms = std::chrono::duration<double, std::milli>(w->t_end - t0).count();
+        if (r != FDR_OK) return r;
+        hipLaunchKernelGGL(checksum_kernel, dim3(1024), dim3(256), 0, stream, d_out, total, d_part);
+        FDR_HIP(hipGetLastError());
+        std::vector<double> part(1024);
+        FDR_HIP(hipMemcpyAsync(part.data(), d_part, 1024 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        FDR_HIP(hipStreamSynchronize(stream));
+        double acc = 0.0;
+        for (double v : part) acc += v;
+        w->checksum = acc;
+        return FDR_OK;
+    };
+    if (hipSetDevice(w->device) != hipSuccess) rc = fail(FDR_ERR_HIP, "fdr_batch_run: hipSetDevice failed");
+    else rc = body();
+    if (rc != FDR_OK) w->error = g_last_error;  // thread-local: hand it to the calling thread
+    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_part);
+    if (stream) (void)hipStreamDestroy(stream);
+    fdr_plan_destroy(plan);
+    w->status = rc;
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int fdr_batch_run(const fdr_batch_desc* d, fdr_batch_stats* st) {
+    if (!d) return fail(FDR_ERR_ARG, "fdr_batch_run: null descriptor");
+    if (d->n_devices < 1 || d->n_devices > FDR_BATCH_MAX_DEVICES || !d->devices)
+        return fail(FDR_ERR_ARG, "fdr_batch_run: need 1..16 device entries");
+    if (d->count < 0 || d->rows <= 0 || d->cols <= 0 || d->rows > d->M || d->cols > d->N)
+        return fail(FDR_ERR_ARG, "fdr_batch_run: bad batch shape");
+    if (d->imgs_host && (!d->outs_host || d->stride < d->cols || d->out_stride < d->cols))
+        return fail(FDR_ERR_ARG, "fdr_batch_run: host images need outs_host and strides >= cols");
+    if (!d->imgs_host && d->steps < 1) return fail(FDR_ERR_ARG, "fdr_batch_run: synthetic run needs steps >= 1");
+    if (!d->psf_host && d->psf_size <= 0) return fail(FDR_ERR_ARG, "fdr_batch_run: no PSF given");
+    int ndev = 0;
+    FDR_HIP(hipGetDeviceCount(&ndev));
+    for (int g = 0; g < d->n_devices; ++g)
+        if (d->devices[g] < 0 || d->devices[g] >= ndev) return fail(FDR_ERR_ARG, "fdr_batch_run: device ordinal out of range");
+    const int G = d->n_devices;
+    std::vector<BatchWorker> ws((size_t)G);
+    std::vector<std::chrono::steady_clock::time_point> starts((size_t)G);
+    // fft/fft_mpi.cpp:89-100 applied to images: floor(count / G) each, the first count % G workers one more
+    for (int g = 0, first = 0; g < G; ++g) {
+        ws[g].index = g; ws[g].device = d->devices[g];
+        ws[g].count = d->count / G + (g < d->count % G ? 1 : 0);
+        ws[g].first = first;
+        first += ws[g].count;
+    }
+    const auto t_launch = std::chrono::steady_clock::now();
+    for (int g = 0; g < G; ++g) { starts[g] = t_launch; ws[g].t_end = t_launch; }
+    std::vector<std::thread> threads;
+    for (int g = 1; g < G; ++g) threads.emplace_back(batch_worker_run, d, &ws[g], &starts[g]);
+    batch_worker_run(d, &ws[0], &starts[0]);  // worker 0 on the calling thread
+    for (auto& t : threads) t.join();
+    int rc = FDR_OK;
+    std::string msg;
+    auto t_first = starts[0], t_last = ws[0].t_end;
+    bool any = false;
+    long long done = 0;
+    for (int g = 0; g < G; ++g) {
+        if (ws[g].status != FDR_OK && rc == FDR_OK) { rc = ws[g].status; msg = "worker " + std::to_string(g) + " (device " + std::to_string(ws[g].device) + "): " + ws[g].error; }
+        if (ws[g].count > 0 && ws[g].status == FDR_OK) {
+            if (!any || starts[g] < t_first) t_first = starts[g];
+            if (!any || ws[g].t_end > t_last) t_last = ws[g].t_end;
+            any = true;
+            done += (long long)ws[g].count * (d->imgs_host ? 1 : d->steps);
+        }
+    }
+    if (st) {
+        memset(st, 0, sizeof *st);
+        st->n_devices = G;
+        for (int g = 0; g < G; ++g) {
+            st->first[g] = ws[g].first; st->images[g] = ws[g].count; st->elapsed_ms[g] = ws[g].elapsed_ms;
+            st->checksum[g] = ws[g].checksum; st->status[g] = ws[g].status;
+        }
+        st->wall_ms = any ? std::chrono::duration<double, std::milli>(t_last - t_first).count() : 0.0;
+        st->images_done = done;
+        st->mpixels_per_s = st->wall_ms > 0.0 ? (double)done * d->rows * d->cols / 1e6 / (st->wall_ms * 1e-3) : 0.0;
+    }
+    if (rc != FDR_OK) return fail(rc, "fdr_batch_run: " + msg);
     return FDR_OK;
 }
 

@@ -396,8 +396,31 @@ hipError_t launch_synth(uint64_t seed, uint64_t first, size_t count, float* d_ou
     return hipGetLastError();
 }
 
-// ---- fft_serial::dft_naive_inplace (fft/fft_serial.cpp:71-87): one thread per output k, terms
-// accumulated in the reference's order t = 0..n-1; angle evaluated in double, rounded to float.
+// ---- fft_serial::dft_naive_inplace (fft/fft_serial.cpp:71-87): one thread per output k, terms accumulated in the
+// reference's order t = 0..n-1, every product and sum rounded separately (-ffp-contract=off).
+// Table form (bit parity): table[t * n + k] = (cosf(ang), sinf(ang)) with ang = (float)(2.0f*CV_PI*k*t/n*sign) evaluated
+// left to right in double -- generated on the HOST with the C library's cosf / sinf, the functions the serial path
+// itself calls (the device's own cosf / sinf differ from them by up to 2 ulp).  Forward table only: the inverse angle
+// is the exact negation, cosf is even and sinf odd.  Batched over rows (blockIdx.y); src and dst must differ.
+__global__ void dft_naive_rows_kernel(const float2* __restrict__ src, float2* __restrict__ dst, int n, const float2* __restrict__ table,
+                                      int inverse) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float2* __restrict__ row = src + (size_t)blockIdx.y * n;
+    float sr = 0.f, si = 0.f;
+    for (int t = 0; t < n; ++t) {
+        const float2 w = table[(size_t)t * n + k];
+        const float wr = w.x, wi = inverse ? -w.y : w.y;
+        const float2 a = row[t];
+        const float pr = a.x * wr - a.y * wi, pi = a.x * wi + a.y * wr;
+        sr += pr;
+        si += pi;
+    }
+    dst[(size_t)blockIdx.y * n + k] = make_float2(sr, si);
+}
+
+// the same with the angle's cosine and sine evaluated on the device (lengths whose n x n table would be too large):
+// within 2 ulp per twiddle of the table form
 __global__ void dft_naive_kernel(const float2* __restrict__ src, float2* __restrict__ dst, int n, int inverse) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -416,6 +439,12 @@ __global__ void dft_naive_kernel(const float2* __restrict__ src, float2* __restr
 
 hipError_t launch_dft_naive(const float2* src, float2* dst, int n, int inverse, hipStream_t s) {
     hipLaunchKernelGGL(dft_naive_kernel, dim3((n + 127) / 128), dim3(128), 0, s, src, dst, n, inverse);
+    return hipGetLastError();
+}
+
+hipError_t launch_dft_naive_rows(const float2* src, float2* dst, int rows, int n, const float2* table, int inverse, hipStream_t s) {
+    if (rows <= 0 || n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(dft_naive_rows_kernel, dim3((n + 127) / 128, rows), dim3(128), 0, s, src, dst, n, table, inverse);
     return hipGetLastError();
 }
 

@@ -9,7 +9,7 @@
 // affects speed, and it is not enough: with >= 128 KB of lines in flight per CU the sharing cannot
 // be served from a 4 MiB L2, which is why the fast mode moved to the panel-major layout of
 // fdr_panel.hip.  These kernels remain the parity-mode column passes (reference pass order) and the
-// FDR_FLAG_ROWMAJOR A/B variant of the fast mode.
+// column half of fdr_fft2d_c2c in both modes.
 #include "fdr_fft_core.hpp"
 #include "fdr_kernels.hpp"
 
@@ -132,53 +132,6 @@ __global__ __launch_bounds__(ColGeom<LOGM>::THREADS, ColGeom<LOGM>::WAVES_PER_SI
                 }
         }
         block_minmax_store(mn, mx, a.mm_part);
-    } else {  // COL_FUSED
-        // multiply by the precomputed Wiener filter W = conj(H) / (|H|^2 + K) at the output rows
-#pragma unroll
-        for (int u = 0; u < Core::NUL; ++u)
-#pragma unroll
-            for (int q = 0; q < Core::RHOL; ++q) {
-                const int s = u * Core::RHOL + q;
-                if (active) {
-                    float2 w0, w1, w2, w3;
-                    load4(a.filt + (size_t)Core::out_index(tid, u, q) * N + col0, w0, w1, w2, w3);
-                    v[0][s] = cmul_fma(v[0][s], w0);
-                    v[1][s] = cmul_fma(v[1][s], w1);
-                    v[2][s] = cmul_fma(v[2][s], w2);
-                    v[3][s] = cmul_fma(v[3][s], w3);
-                }
-            }
-        constexpr int SEQ1 = Core::SLOTS;
-        if constexpr (Core::RHOL != Core::RHO0) {
-            // the last forward step left X[(t + T u) + (L/RHOL) q]; the first inverse step wants
-            // x[(t + T u') + (L/RHO0) q'].  Both index sets are contiguous in t: one natural-order
-            // LDS round trip per column, no padding needed.
-#pragma unroll
-            for (int b = 0; b < B; ++b) {
-                float2* buf = grp_lds + ((SEQ1 + b) & 1) * St::BUF;
-#pragma unroll
-                for (int u = 0; u < Core::NUL; ++u)
-#pragma unroll
-                    for (int q = 0; q < Core::RHOL; ++q) buf[Core::out_index(tid, u, q)] = v[b][u * Core::RHOL + q];
-                __syncthreads();
-#pragma unroll
-                for (int u = 0; u < Core::NU0; ++u)
-#pragma unroll
-                    for (int q = 0; q < Core::RHO0; ++q) v[b][u * Core::RHO0 + q] = buf[Core::in_index(tid, u, q)];
-            }
-            Core::template run<SEQ1 + B, true>(v, grp_lds, tw_inv, bases, tid);
-        } else {
-            Core::template run<SEQ1, true>(v, grp_lds, tw_inv, bases, tid);
-        }
-        if (active) {
-#pragma unroll
-            for (int u = 0; u < Core::NUL; ++u)
-#pragma unroll
-                for (int q = 0; q < Core::RHOL; ++q) {
-                    const int s = u * Core::RHOL + q;
-                    store4(a.data + (size_t)Core::out_index(tid, u, q) * N + col0, v[0][s], v[1][s], v[2][s], v[3][s]);
-                }
-        }
     }
 }
 
@@ -205,7 +158,6 @@ static hipError_t launch_cols_kind(int mode, ColKind kind, const ColArgs& a, con
     switch (kind) {
         case COL_FWD: return launch_cols_one<LOGM, PolicyFast, COL_FWD>(a, twf, twi, s);
         case COL_INV: return launch_cols_one<LOGM, PolicyFast, COL_INV>(a, twf, twi, s);
-        case COL_FUSED: return launch_cols_one<LOGM, PolicyFast, COL_FUSED>(a, twf, twi, s);  // FDR_FLAG_ROWMAJOR only
         default: return hipErrorInvalidValue;
     }
 }

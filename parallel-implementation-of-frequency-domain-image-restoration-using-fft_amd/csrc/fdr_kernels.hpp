@@ -14,7 +14,7 @@ enum ColKind {
     COL_INV = 1,         // inverse column FFT, complex in place (fft2d)
     COL_FWD_WIENER = 2,  // parity pass B: forward column FFT then the Wiener quotient against H
     COL_INV_REAL = 3,    // parity pass D: inverse column FFT, real part to the raw plane, min/max
-    COL_FUSED = 4        // fast pass B': forward column FFT, multiply by W, inverse column FFT
+    COL_FUSED = 4        // fast pass B' (panel kernels only): forward column FFT, multiply by W, inverse column FFT
 };
 
 // several images per launch of the fast row passes / the normalisation (blockIdx.y = image): small images are launch
@@ -46,7 +46,6 @@ struct RowArgs {
     int M;              // number of rows to transform
     size_t pstride;     // rows4 kernels: panel stride of the panel-major spectrum, in float2 elements
     int half;           // rows4 packed kernels: half (Hermitian) spectrum, N/8 + 1 panels
-    int no_packing;     // rows4 kernels: one complex transform per row instead of two rows per transform
     RowBatch batch;     // rows4 packed kernels: several images per launch
 };
 
@@ -83,12 +82,9 @@ struct ColArgs {
     int N;  // row length (number of columns)
     int npanels;      // panel kernels: number of panels (0 = N/4)
     PanelBatch batch; // panel kernels, COL_FUSED: several images per launch
-    int v16;          // panel kernels, COL_FUSED: 16-values-per-thread kernel (columns of >= 1024 points)
-    int lean;         // panel kernels, COL_FUSED: single-register-set kernel, one workgroup per tile
     int packed0;      // panel kernels: column 0 of panel 0 is the packed DC + i Nyquist column (half spectrum)
     size_t pstride;   // panel kernels: panel stride in float2 elements
     int num_cu;       // CUs of the device (persistent pass B' launches one workgroup per CU)
-    int no_pipeline;  // debug/bench: use the non-persistent fused kernel
 };
 
 // launchers (fdr_rows.hip / fdr_cols.hip); logl = log2 of the transform length, 3..13
@@ -143,5 +139,7 @@ int color_partials(int rows, int cols);
 hipError_t launch_color_epilogue(const ColorArgs& a, double2* part, hipStream_t s);
 hipError_t launch_synth(uint64_t seed, uint64_t first, size_t count, float* d_out, hipStream_t s);
 hipError_t launch_dft_naive(const float2* src, float2* dst, int n, int inverse, hipStream_t s);
+// table[t * n + k], forward direction, host generated (see fdr_aux.hip); rows transforms of length n, src != dst
+hipError_t launch_dft_naive_rows(const float2* src, float2* dst, int rows, int n, const float2* table, int inverse, hipStream_t s);
 
 }  // namespace fdr

@@ -28,93 +28,6 @@ namespace fdr {
 // ---------------------------------------------------------------------------------------------
 // rows, 4 at a time
 // ---------------------------------------------------------------------------------------------
-template <int LOGL>
-struct Rows4Geom {
-    static constexpr int T = Steps<LOGL>::T;
-    static constexpr int G = T >= 256 ? 1 : 256 / T;  // 4-row groups per workgroup
-    static constexpr int THREADS = T * G;
-    // 512 threads = 2 waves/SIMD per workgroup; two workgroups per CU need <= 128 VGPRs
-    static constexpr int WAVES_PER_SIMD = THREADS >= 512 ? 4 : 1;
-};
-
-template <int LOGL, int IN, int OUT, bool INV>
-__global__ __launch_bounds__(Rows4Geom<LOGL>::THREADS, Rows4Geom<LOGL>::WAVES_PER_SIMD) void fft_rows4_kernel(
-    const RowArgs a, const float2* __restrict__ tw_fwd) {
-    using St = Steps<LOGL>;
-    using Geo = Rows4Geom<LOGL>;
-    constexpr int B = 4, G = Geo::G, T = St::T, L = St::L;
-    using Core = FftCore<LOGL, B, 2, PolicyFast>;
-    __shared__ float2 lds[G * 2 * St::BUF];
-
-    const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
-    const int M = a.M;
-    const int r0 = (blockIdx.x * G + g) * 4;
-    const bool active = r0 < M;  // M is a multiple of 4 on this path
-    const int rr = active ? r0 : 0;  // inactive groups read rows 0..3 (valid memory), store nothing
-
-    typename Core::Bases bases;
-    Core::init_bases(bases, tw_fwd, tid);
-
-    float2 v[B][8];
-#pragma unroll
-    for (int u = 0; u < Core::NU0; ++u)
-#pragma unroll
-        for (int q = 0; q < Core::RHO0; ++q) {
-            const int s = u * Core::RHO0 + q;
-            const int n = Core::in_index(tid, u, q);
-            if (IN == ROW_IN_REAL) {
-#pragma unroll
-                for (int b = 0; b < B; ++b) {
-                    float x = 0.f;
-                    if (rr + b < a.src_rows && n < a.src_cols) x = a.src_real[(size_t)(rr + b) * a.src_stride + n];
-                    v[b][s] = make_float2(x, 0.f);
-                }
-            } else {
-                const float2* p = a.src_c + (size_t)(n >> 2) * a.pstride + (size_t)rr * 4 + (n & 3);
-#pragma unroll
-                for (int b = 0; b < B; ++b) v[b][s] = p[b * 4];
-            }
-        }
-
-    Core::template run<0, INV>(v, lds + g * 2 * St::BUF, tw_fwd, bases, tid);
-
-    if (OUT == ROW_OUT_COMPLEX) {  // panel-major spectrum
-        if (active) {
-#pragma unroll
-            for (int u = 0; u < Core::NUL; ++u)
-#pragma unroll
-                for (int q = 0; q < Core::RHOL; ++q) {
-                    const int s = u * Core::RHOL + q;
-                    const int n = Core::out_index(tid, u, q);
-                    float2* p = a.dst_c + (size_t)(n >> 2) * a.pstride + (size_t)r0 * 4 + (n & 3);
-#pragma unroll
-                    for (int b = 0; b < B; ++b) p[b * 4] = v[b][s];
-                }
-        }
-    } else {
-        float mn = __builtin_inff(), mx = -__builtin_inff();
-        if (active) {
-#pragma unroll
-            for (int u = 0; u < Core::NUL; ++u)
-#pragma unroll
-                for (int q = 0; q < Core::RHOL; ++q) {
-                    const int s = u * Core::RHOL + q;
-                    const int n = Core::out_index(tid, u, q);
-#pragma unroll
-                    for (int b = 0; b < B; ++b) {
-                        const float r = v[b][s].x;
-                        a.dst_real[(size_t)(r0 + b) * L + n] = r;
-                        if (r0 + b < a.mm_rows && n < a.mm_cols) {
-                            mn = fminf(mn, r);
-                            mx = fmaxf(mx, r);
-                        }
-                    }
-                }
-        }
-        block_minmax_store(mn, mx, a.mm_part);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Two-for-one row transforms (fast mode only; rounding differs from the serial path at the 1e-7
 // level, far inside the 1e-4 budget).  The image rows are real, and after the inverse column pass
@@ -671,17 +584,14 @@ __global__ __launch_bounds__(256) void normalize_fixup_kernel(const RowArgs a, c
 
 template <int LOGL>
 static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const float2* tw, hipStream_t s) {
-    using Geo = Rows4Geom<LOGL>;
+    using Geo = Rows4PackGeom<LOGL>;
     const int groups = (a.M + 3) / 4;
-    const dim3 grid((groups + Geo::G - 1) / Geo::G, a.batch.nimg > 1 && !a.no_packing ? a.batch.nimg : 1), block(Geo::THREADS);
-    static_assert(Rows4PackGeom<LOGL>::G == Geo::G && Rows4PackGeom<LOGL>::THREADS == Geo::THREADS, "same launch shape");
+    const dim3 grid((groups + Geo::G - 1) / Geo::G, a.batch.nimg > 1 ? a.batch.nimg : 1), block(Geo::THREADS);
     if (in == ROW_IN_REAL && out == ROW_OUT_COMPLEX) {
-        if (a.no_packing) hipLaunchKernelGGL((fft_rows4_kernel<LOGL, ROW_IN_REAL, ROW_OUT_COMPLEX, false>), grid, block, 0, s, a, tw);
-        else if (a.half) hipLaunchKernelGGL((fft_rows4_fwd_packed_kernel<LOGL, true>), grid, block, 0, s, a, tw);
+        if (a.half) hipLaunchKernelGGL((fft_rows4_fwd_packed_kernel<LOGL, true>), grid, block, 0, s, a, tw);
         else hipLaunchKernelGGL((fft_rows4_fwd_packed_kernel<LOGL, false>), grid, block, 0, s, a, tw);
     } else if (in == ROW_IN_COMPLEX && out == ROW_OUT_REAL_MINMAX) {
-        if (a.no_packing) hipLaunchKernelGGL((fft_rows4_kernel<LOGL, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, true>), grid, block, 0, s, a, tw);
-        else if (a.half) hipLaunchKernelGGL((fft_rows4_inv_packed_kernel<LOGL, true>), grid, block, 0, s, a, tw);
+        if (a.half) hipLaunchKernelGGL((fft_rows4_inv_packed_kernel<LOGL, true>), grid, block, 0, s, a, tw);
         else hipLaunchKernelGGL((fft_rows4_inv_packed_kernel<LOGL, false>), grid, block, 0, s, a, tw);
     } else {
         return hipErrorInvalidValue;
@@ -690,7 +600,7 @@ static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const f
 }
 
 template <int LOGL>
-static int rows4_partials_t(int M) { return ((M + 3) / 4 + Rows4Geom<LOGL>::G - 1) / Rows4Geom<LOGL>::G; }
+static int rows4_partials_t(int M) { return ((M + 3) / 4 + Rows4PackGeom<LOGL>::G - 1) / Rows4PackGeom<LOGL>::G; }
 
 #define FDR_DISPATCH_LOG(var, expr)                                                     \
     switch (var) {                                                                      \
@@ -1108,125 +1018,6 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::PIPE_WAV
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pass B' for 8192-point columns: one transform needs 1024 threads, i.e. 16 waves = 4 per SIMD and a
-// 128-VGPR budget, which cannot hold two register sets (the pipelined kernel above spills ~1 KB per
-// lane there).  This variant keeps ONE set (64 VGPRs of payload) and pulls the filter in 32-byte pieces
-// straight into the multiply, one workgroup per panel.
-// ---------------------------------------------------------------------------------------------
-template <int LOGM>
-__global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PER_SIMD) void fft_cols_panel_fused_lean_kernel(
-    const PanelBatch pb, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const unsigned pstride,
-    const int npanels, const int ntiles, const int packed0) {
-    using St = Steps<LOGM>;
-    using Geo = PanelGeom<LOGM>;
-    constexpr int G = Geo::G, T = St::T, M = St::L;
-    using Core = FftCore<LOGM, 4, 2, PolicyFast>;
-    __shared__ float2 lds[G * 2 * St::BUF];
-    const int g = G == 1 ? 0 : (int)(threadIdx.x >> St::LOGT);
-    const int tid = threadIdx.x & (T - 1);
-    float2* grp_lds = lds + g * 2 * St::BUF;
-    // grid (ntiles, images): an integer division here would run on the VALU and drag every tile address into VGPRs
-    const int img = blockIdx.y, tl = blockIdx.x;
-    const bool active = tl * G + g < npanels;
-    // uniform tile bases + one 32-bit per-lane element offset (see tile_load)
-    const size_t tbase = (size_t)(tl * G) * pstride;
-    float2* __restrict__ data = (img == 0 ? pb.data[0] : img == 1 ? pb.data[1] : img == 2 ? pb.data[2] : pb.data[3]) + tbase;
-    const float2* __restrict__ tfilt = filt + tbase;
-    const unsigned loff = (active ? (unsigned)g : 0u) * pstride + (unsigned)tid * 4u;
-
-    typename Core::Bases bases;
-    Core::init_bases(bases, tw_fwd, tid);
-
-    float2 v[4][8];
-    tile_load<Core, false>(data, loff, 1u, v);
-    Core::template run<0, false>(v, grp_lds, tw_fwd, bases, tid);
-
-    const bool packed_tile = packed0 && tl == 0;  // uniform per workgroup
-    constexpr int SEQ = Core::SLOTS;
-    if (packed_tile) {
-        // Column 0 of panel 0 (packed DC + i Nyquist, see packed_column_filter) is finished here on its own -- mirror
-        // exchange through LDS, two filters, re-pack -- and then rides through the common multiply below with W = 1.
-        // Only v[0][*] changes, so this once-per-image path adds little to the register pressure of the common one.
-        float2* bufc = grp_lds + (SEQ & 1) * St::BUF;
-        float2* bufs = grp_lds + ((SEQ + 1) & 1) * St::BUF;
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < Core::NUL; ++u)
-#pragma unroll
-            for (int q = 0; q < Core::RHOL; ++q) {
-                const int s = u * Core::RHOL + q;
-                const int k = Core::out_index(tid, u, q);
-                bufc[k] = v[0][s];
-                bufs[k] = tfilt[loff - (unsigned)tid * 4u + (unsigned)k * 4u];  // (read back below: no registers held)
-            }
-        __syncthreads();
-        if (g == 0) {
-#pragma unroll
-            for (int u = 0; u < Core::NUL; ++u)
-#pragma unroll
-                for (int q = 0; q < Core::RHOL; ++q) {
-                    const int s = u * Core::RHOL + q;
-                    const int k = Core::out_index(tid, u, q);
-                    const int km = (M - k) & (M - 1);
-                    const float2 c = v[0][s], cm = bufc[km], sm = bufs[km], sl_s = bufs[k];
-                    const float2 f0 = make_float2(0.5f * (c.x + cm.x), 0.5f * (c.y - cm.y));
-                    const float2 fn = make_float2(0.5f * (c.y + cm.y), 0.5f * (cm.x - c.x));
-                    float2 a0, an;
-                    if (k == 0 || k == M / 2) { a0 = make_float2(sl_s.x, 0.f); an = make_float2(sl_s.y, 0.f); }
-                    else if (k < M / 2) { a0 = sl_s; an = sm; }
-                    else { a0 = make_float2(sm.x, -sm.y); an = make_float2(sl_s.x, -sl_s.y); }
-                    const float2 z0 = cmul_fma(f0, a0), zn = cmul_fma(fn, an);
-                    v[0][s] = make_float2(z0.x - zn.y, z0.y + zn.x);
-                }
-        }
-        __syncthreads();  // both buffers were read above
-    }
-    {
-        const bool col0_done = packed_tile && g == 0;
-        // W in four pieces of two slots (16 VGPRs each), the next piece requested before the current one is used; the
-        // compiler barriers keep it from hoisting all 16 loads to the top (64 more live registers = spills at 128)
-        auto wload = [&](int h, float2 (&w)[2][4]) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int s = 2 * h + i, u = s / Core::RHOL, q = s % Core::RHOL;
-                const unsigned uoff = (unsigned)(((q << Core::LOGOUT) + u * Core::T) * 4);
-                const gchar* ub = uniform_gptr(tfilt + uoff);
-                FDR_GLOAD32(ub, loff * 8u, w[i][0], w[i][1], w[i][2], w[i][3]);
-            }
-        };
-        auto wmul = [&](int h, const float2 (&w)[2][4]) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int s = 2 * h + i;
-                v[0][s] = cmul_fma(v[0][s], col0_done ? make_float2(1.f, 0.f) : w[i][0]);
-                v[1][s] = cmul_fma(v[1][s], w[i][1]);
-                v[2][s] = cmul_fma(v[2][s], w[i][2]);
-                v[3][s] = cmul_fma(v[3][s], w[i][3]);
-            }
-        };
-        float2 wa[2][4], wb[2][4];
-        wload(0, wa);
-        asm volatile("" ::: "memory");
-        wload(1, wb);
-        wmul(0, wa);
-        asm volatile("" ::: "memory");
-        wload(2, wa);
-        wmul(1, wb);
-        asm volatile("" ::: "memory");
-        wload(3, wb);
-        wmul(2, wa);
-        wmul(3, wb);
-    }
-    if constexpr (Core::RHOL != Core::RHO0) {
-        redistribute<LOGM, Core, SEQ>(v, grp_lds, tid);
-        Core::template run<SEQ + 4, true>(v, grp_lds, tw_fwd, bases, tid);
-    } else {
-        Core::template run<SEQ, true>(v, grp_lds, tw_fwd, bases, tid);
-    }
-    if (active) tile_store<Core>(data, loff, v);
-}
-
-// ---------------------------------------------------------------------------------------------
 // Pass B' with 16 values per thread (radix-16 steps): a 4096-point column takes 256 threads, so a 4-column tile is
 // ONE 256-thread workgroup holding 128 data registers per lane, and two such workgroups share a CU (2 x 74 KB of LDS,
 // 256 VGPRs each): the hardware overlaps one tile's loads / stores with the other tile's transforms, which the
@@ -1374,7 +1165,7 @@ template <int LOGM>
 static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const float2* tw, hipStream_t s) {
     using Geo = PanelGeom<LOGM>;
     const size_t ps = a.pstride;
-    const int npanels = a.npanels > 0 ? a.npanels : a.N / 4;  // half spectrum: N/8 + 1
+    const int npanels = a.npanels > 0 ? a.npanels : a.N / 4;  // half spectrum: N/8
     const int ntiles = (npanels + Geo::G - 1) / Geo::G;
     if (kind == COL_FWD) {
         hipLaunchKernelGGL((fft_cols_panel_fwd_kernel<LOGM>), dim3(ntiles), dim3(Geo::THREADS), 0, s, a.data, tw, ps, npanels);
@@ -1382,27 +1173,18 @@ static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const floa
         PanelBatch pb = a.batch;
         if (pb.nimg <= 0) { pb.nimg = 1; pb.data[0] = a.data; }
         for (int k = pb.nimg; k < 4; ++k) pb.data[k] = pb.data[0];
-        const int total = ntiles * pb.nimg;
-        if constexpr (LOGM >= 10) {
-            if (a.v16) {  // 16 values per thread, two 256-thread workgroups per CU
-                using G16 = Panel16Geom<LOGM>;
-                const int nt16 = (npanels + G16::G - 1) / G16::G;
-                hipLaunchKernelGGL((fft_cols_panel_fused16_kernel<LOGM>), dim3(nt16, pb.nimg), dim3(G16::THREADS), 0, s, pb, a.filt,
-                                   tw, (unsigned)ps, npanels, nt16, a.packed0);
-                return hipGetLastError();
-            }
+        if constexpr (LOGM >= 10) {  // 16 values per thread: one workgroup per tile, grid (tiles, images)
+            using G16 = Panel16Geom<LOGM>;
+            const int nt16 = (npanels + G16::G - 1) / G16::G;
+            hipLaunchKernelGGL((fft_cols_panel_fused16_kernel<LOGM>), dim3(nt16, pb.nimg), dim3(G16::THREADS), 0, s, pb, a.filt, tw,
+                               (unsigned)ps, npanels, nt16, a.packed0);
+        } else {                     // short columns: persistent radix-8 kernel, register double-buffered
+            const int total = ntiles * pb.nimg;
+            int grid = (a.num_cu > 0 ? a.num_cu : 256) * Geo::PIPE_WG_PER_CU;
+            if (grid > total) grid = total;
+            hipLaunchKernelGGL((fft_cols_panel_fused_kernel<LOGM>), dim3(grid), dim3(Geo::THREADS), 0, s, pb, a.filt, tw, (unsigned)ps,
+                               npanels, ntiles, a.packed0);
         }
-        // single register set, one workgroup per tile, two workgroups per CU: always for 8192-point columns (1024
-        // threads per transform leave no room for a second set), on request (FDR_FLAG_LEAN_COLS) otherwise
-        if (Geo::THREADS >= 1024 || a.lean) {
-            hipLaunchKernelGGL((fft_cols_panel_fused_lean_kernel<LOGM>), dim3(ntiles, pb.nimg), dim3(Geo::THREADS), 0, s, pb, a.filt, tw,
-                               (unsigned)ps, npanels, ntiles, a.packed0);
-            return hipGetLastError();
-        }
-        int grid = (a.num_cu > 0 ? a.num_cu : 256) * Geo::PIPE_WG_PER_CU;
-        if (a.no_pipeline || grid > total) grid = total;
-        hipLaunchKernelGGL((fft_cols_panel_fused_kernel<LOGM>), dim3(grid), dim3(Geo::THREADS), 0, s, pb, a.filt, tw, (unsigned)ps,
-                           npanels, ntiles, a.packed0);
     } else {
         return hipErrorInvalidValue;
     }

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(fdr):
     missing = [n for n in declared if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(fdr.EXPORTED_SYMBOLS) == declared
-    assert lib.fdr_version() == 100
+    assert lib.fdr_version() == 200
 
 
 def test_integer_helpers_match_reference_semantics(fdr):

@@ -37,11 +37,23 @@ int main(int argc, char** argv) {
     Mat padded = autoPadToPowerOfTwo(img);
     if (padded.rows != 128 || padded.cols != 256 || padded.ptr<float>(127)[255] != 0.0f || padded.ptr<float>(99)[199] != img.ptr<float>(99)[199]) return 5;
 
-    // fft_gpu::wienerDeblur_myfft (fft/fft.hpp:44) in both arithmetic modes
-    fft_gpu::set_mode(FDR_MODE_PARITY);
-    dump(out + "wiener_parity.f32", fft_gpu::wienerDeblur_myfft(img, psf, 0.01f));
+    // fft_gpu::wienerDeblur_myfft (fft/fft.hpp:44) with the semantics of fft/fft_serial.cpp:141-261.
+    // (1) called directly on the un-padded 100 x 200 channel: getOptimalDFTSize leaves 100 = 2^2 5^2 and 200 = 2^3 5^2
+    //     alone, both dimensions go through the naive DFT (:100-101), the crop is a no-op, normalised as a whole
+    fft_gpu::Options par; par.mode = FDR_MODE_PARITY;
+    dump(out + "wiener_unpadded.f32", fft_gpu::wienerDeblur_myfft(img, psf, 0.01f, par));
+    // (2) the way serial.cpp:34-39 calls it: pad to powers of two first, crop afterwards -- through the fft_serial names
+    {
+        Mat restored = fft_serial::wienerDeblur_myfft(padded, psf, 0.01f);
+        if (restored.rows != 128 || restored.cols != 256) return 8;
+        dump(out + "wiener_parity.f32", restored(Rect(0, 0, img.cols, img.rows)).clone());
+    }
+    // (3) fast arithmetic through the process-wide default of the reference-signature overload
     fft_gpu::set_mode(FDR_MODE_FAST);
-    dump(out + "wiener_fast.f32", fft_gpu::wienerDeblur_myfft(img, psf, 0.01f));
+    {
+        Mat restored = fft_gpu::wienerDeblur_myfft(padded, psf, 0.01f);
+        dump(out + "wiener_fast.f32", restored(Rect(0, 0, img.cols, img.rows)).clone());
+    }
 
     // fft_gpu::wienerDeblur_RGB_optimized / _naive (fft/fft.hpp:32-33): three channels replaced in place
     std::vector<Mat> ch;
