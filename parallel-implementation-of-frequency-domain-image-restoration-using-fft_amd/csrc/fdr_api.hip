@@ -285,7 +285,7 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
     } else if (p->panel) {
         RowArgs ra{};
         ra.src_real = d_psf; ra.src_rows = prows; ra.src_cols = pcols; ra.src_stride = pstride;
-        ra.dst_c = p->filt; ra.M = p->M; ra.pstride = p->pstride; ra.half = p->half;
+        ra.dst_c = p->filt; ra.M = p->M; ra.pstride = p->pstride; ra.half = p->half; ra.num_cu = p->num_cu;
         FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, ra, p->tw_row_f, s));
         ColArgs ca{};
         ca.data = p->filt; ca.N = p->N; ca.num_cu = p->num_cu; ca.pstride = p->pstride; ca.npanels = p->npanels;
@@ -337,7 +337,7 @@ int panel_stage_A(fdr_plan* p, fdr_plan::Slot& w, const float* d_img, int rows, 
     ScopedPass t(p, s, kPassRowsFwd);   // A: 4 rows per thread group, real -> panel-major (half) spectrum
     RowArgs a{};
     a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
-    a.dst_c = w.work; a.M = p->M; a.pstride = p->pstride; a.half = p->half;
+    a.dst_c = w.work; a.M = p->M; a.pstride = p->pstride; a.half = p->half; a.num_cu = p->num_cu;
     FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
     return FDR_OK;
 }
@@ -388,12 +388,12 @@ int panel_stage_CE(fdr_plan* p, fdr_plan::Slot& w, int rows, int cols, float* d_
         ScopedPass t(p, s, kPassRowsInvReal);
         RowArgs a{};
         a.src_c = w.work; a.dst_real = w.raw; a.mm_part = w.mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
-        a.pstride = p->pstride; a.half = p->half;
+        a.pstride = p->pstride; a.half = p->half; a.num_cu = p->num_cu;
         FDR_HIP(launch_rows4(p->logN, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, a, p->tw_row_f, s));
     }
     {   // E: normalise to [0,1] and crop
         ScopedPass t(p, s, kPassNormalize);
-        const int n_part = rows4_minmax_partials(p->logN, p->M);
+        const int n_part = rows4_minmax_partials(p->logN, p->M, p->num_cu, 1);
         if (n_part <= 0 || n_part > p->mm_part_cap || n_part > 4096) return fail(FDR_ERR_STATE, "fdr_wiener: min/max partial count out of range");
         FDR_HIP(launch_normalize(w.raw, p->N, w.mm_part, n_part, nullptr, d_out, rows, cols, out_stride, s));
     }
@@ -407,7 +407,7 @@ int panel_stage_A_batch(fdr_plan* p, fdr_plan::Slot* const* ws, int n, const flo
     ScopedPass t(p, s, kPassRowsFwdN[n]);
     RowArgs a{};
     a.src_real = d_imgs[0]; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
-    a.dst_c = ws[0]->work; a.M = p->M; a.pstride = p->pstride; a.half = 1;
+    a.dst_c = ws[0]->work; a.M = p->M; a.pstride = p->pstride; a.half = 1; a.num_cu = p->num_cu;
     a.batch.nimg = n;
     for (int k = 0; k < 4; ++k) { a.batch.src_real[k] = d_imgs[k < n ? k : 0]; a.batch.spec[k] = ws[k < n ? k : 0]->work; }
     FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
@@ -419,7 +419,7 @@ int panel_stage_CE_batch(fdr_plan* p, fdr_plan::Slot* const* ws, int n, int rows
         ScopedPass t(p, s, kPassRowsInvRealN[n]);
         RowArgs a{};
         a.src_c = ws[0]->work; a.dst_real = ws[0]->raw; a.mm_part = ws[0]->mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
-        a.pstride = p->pstride; a.half = 1;
+        a.pstride = p->pstride; a.half = 1; a.num_cu = p->num_cu;
         a.batch.nimg = n;
         for (int k = 0; k < 4; ++k) {
             const fdr_plan::Slot* w = ws[k < n ? k : 0];
@@ -429,7 +429,7 @@ int panel_stage_CE_batch(fdr_plan* p, fdr_plan::Slot* const* ws, int n, int rows
     }
     {
         ScopedPass t(p, s, kPassNormalizeN[n]);
-        const int n_part = rows4_minmax_partials(p->logN, p->M);
+        const int n_part = rows4_minmax_partials(p->logN, p->M, p->num_cu, n);
         if (n_part <= 0 || n_part > p->mm_part_cap || n_part > 4096) return fail(FDR_ERR_STATE, "fdr_wiener: min/max partial count out of range");
         NormBatch nb{};
         nb.nimg = n;

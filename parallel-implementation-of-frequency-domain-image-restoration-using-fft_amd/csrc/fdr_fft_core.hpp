@@ -206,6 +206,93 @@ __device__ __forceinline__ void radix_step(float2* x, const TwSet& t) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// First step of a transform in the fast mode: the sub-transforms have size LP = 1, so the step's base twiddle is
+// T[0] = 1 and every derived twiddle is a constant -- 1, -+i, e^(-+i pi/4), e^(-+i pi/8) ...  Multiplications by 1 and
+// by -+i are additions with swapped / negated operands; the others use literal constants.  No table value is loaded
+// and no register holds a base for this step (a third of the butterflies of a three-step transform).
+// (Parity mode never comes here: there every product with the table value is computed, as the reference does.)
+// ---------------------------------------------------------------------------------------------
+template <bool INV>
+struct TrivialTw {
+    // u' = u + v, v' = u - v
+    static __device__ __forceinline__ void one(float2& u, float2& v) {
+        const float2 a = make_float2(u.x + v.x, u.y + v.y), b = make_float2(u.x - v.x, u.y - v.y);
+        u = a; v = b;
+    }
+    // v times -i (forward) / +i (inverse), then the butterfly
+    static __device__ __forceinline__ void rot(float2& u, float2& v) {
+        float2 a, b;
+        if (INV) { a = make_float2(u.x - v.y, u.y + v.x); b = make_float2(u.x + v.y, u.y - v.x); }
+        else     { a = make_float2(u.x + v.y, u.y - v.x); b = make_float2(u.x - v.y, u.y + v.x); }
+        u = a; v = b;
+    }
+    static __device__ __forceinline__ float2 cis(float c, float s) { return make_float2(c, INV ? s : -s); }  // e^(-+i phi)
+    static __device__ __forceinline__ float2 rotc(float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
+};
+
+template <int LR, class Pol, bool INV>
+__device__ __forceinline__ void radix_step_first(float2* x) {
+    using Tw = TrivialTw<INV>;
+    if constexpr (LR == 1) {
+        Tw::one(x[0], x[1]);
+    } else if constexpr (LR == 2) {
+        Tw::one(x[0], x[2]);
+        Tw::one(x[1], x[3]);
+        Tw::one(x[0], x[1]);
+        Tw::rot(x[2], x[3]);
+        swap2(x[1], x[2]);
+    } else {
+        const float c = 0.70710678118654752440f;
+        const float2 d = Tw::cis(c, c);  // e^(-+i pi/4)
+        Tw::one(x[0], x[4]);
+        Tw::one(x[1], x[5]);
+        Tw::one(x[2], x[6]);
+        Tw::one(x[3], x[7]);
+        Tw::one(x[0], x[2]);
+        Tw::one(x[1], x[3]);
+        Tw::rot(x[4], x[6]);
+        Tw::rot(x[5], x[7]);
+        Tw::one(x[0], x[1]);
+        Pol::bfly(x[4], x[5], d);
+        Tw::rot(x[2], x[3]);
+        Pol::bfly(x[6], x[7], Tw::rotc(d));
+        swap2(x[1], x[4]);
+        swap2(x[3], x[6]);
+    }
+}
+
+template <class P, int B, int V, bool INV>
+__device__ __forceinline__ void radix16_first(float2 (&v)[B][V]) {
+    static_assert(V == 16, "16 values per thread");
+    using Tw = TrivialTw<INV>;
+    const float c4 = 0.70710678118654752440f, c8 = 0.92387953251128675613f, s8 = 0.38268343236508977173f;
+    const float2 d = Tw::cis(c4, c4), e1 = Tw::cis(c8, s8), e3 = Tw::cis(s8, c8);
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Tw::one(v[b][i], v[b][i + 8]);                     // stage 1: w^8 = 1
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { Tw::one(v[b][i], v[b][i + 4]); Tw::rot(v[b][8 + i], v[b][12 + i]); }  // stage 2: {1, -+i}
+        // stage 3: blocks j = 0..3 -> {1, -+i, e^(-+i pi/4), -+i e^(-+i pi/4)}
+        Tw::one(v[b][0], v[b][2]); Tw::one(v[b][1], v[b][3]);
+        Tw::rot(v[b][4], v[b][6]); Tw::rot(v[b][5], v[b][7]);
+        P::bfly(v[b][8], v[b][10], d); P::bfly(v[b][9], v[b][11], d);
+        P::bfly(v[b][12], v[b][14], Tw::rotc(d)); P::bfly(v[b][13], v[b][15], Tw::rotc(d));
+        // stage 4: blocks j = 0..7 -> omega_16^bitrev3(j) = {0, 4, 2, 6, 1, 5, 3, 7}
+        Tw::one(v[b][0], v[b][1]);
+        Tw::rot(v[b][2], v[b][3]);
+        P::bfly(v[b][4], v[b][5], d);
+        P::bfly(v[b][6], v[b][7], Tw::rotc(d));
+        P::bfly(v[b][8], v[b][9], e1);
+        P::bfly(v[b][10], v[b][11], Tw::rotc(e1));
+        P::bfly(v[b][12], v[b][13], e3);
+        P::bfly(v[b][14], v[b][15], Tw::rotc(e3));
+        swap2(v[b][1], v[b][8]); swap2(v[b][2], v[b][4]); swap2(v[b][3], v[b][12]);
+        swap2(v[b][5], v[b][10]); swap2(v[b][7], v[b][14]); swap2(v[b][11], v[b][13]);
+    }
+}
+
 // Radix-16 step of the fast policy on B transforms at once, STAGE-major (stage t of all B transforms before stage
 // t+1), so that only one stage's twiddles are live: 1, 2, 4, then 8 complex values, all derived from the ONE hoisted
 // table value w = exp(-+2 pi i k / (16 LP)):  stage 1: w^8;  stage 2: w^4 {1, -+i};  stage 3: w^2 {1, e^(-+i pi/4)} x
@@ -298,8 +385,10 @@ struct FftCore {
     template <int J>
     static __device__ __forceinline__ void init_bases_from(Bases& bs, const float2* __restrict__ tw, int tid) {
         constexpr int LR = St::lr(J), NU = St::nu(J), LOGR = St::logR(J), LP = 1 << St::lprev(J);
+        if constexpr (LP != 1) {  // (the first step's twiddles are constants)
 #pragma unroll
-        for (int u = 0; u < NU; ++u) bs.b[J][u] = Pol::template base<LR, LP>(tw, (tid + u * T) >> LOGR);
+            for (int u = 0; u < NU; ++u) bs.b[J][u] = Pol::template base<LR, LP>(tw, (tid + u * T) >> LOGR);
+        }
         if constexpr (J + 1 < S) init_bases_from<J + 1>(bs, tw, tid);
     }
     static __device__ __forceinline__ void init_bases(Bases& bs, const float2* __restrict__ tw, int tid) {
@@ -317,7 +406,16 @@ struct FftCore {
     template <int J, bool INV>
     static __device__ __forceinline__ void butterflies(float2 (&v)[B][V], const float2* __restrict__ tw, const Bases& bs, int tid) {
         constexpr int LR = St::lr(J), NU = St::nu(J), RHO = 1 << LR, LOGR = St::logR(J), LP = 1 << St::lprev(J);
-        if constexpr (LR == 4) {
+        if constexpr (Pol::kHoist && LP == 1) {  // first step of the fast mode: constant twiddles (see TrivialTw)
+            if constexpr (LR == 4) {
+                radix16_first<Pol, B, V, INV>(v);
+            } else {
+#pragma unroll
+                for (int u = 0; u < NU; ++u)
+#pragma unroll
+                    for (int b = 0; b < B; ++b) radix_step_first<LR, Pol, INV>(&v[b][u * RHO]);
+            }
+        } else if constexpr (LR == 4) {
             static_assert(Pol::kHoist, "radix-16 steps exist for the fast policy only");
             radix16_fast<Pol, B, V, INV>(v, bs.b[J][0]);  // NU == 1: the 16 values of a thread are one butterfly
         } else {
@@ -331,10 +429,27 @@ struct FftCore {
         }
     }
 
+    // Exchange between steps J and J+1 of the B transforms, one after the other.  Both index sets are AFFINE in the slot
+    // number q once the thread part is fixed (pad() only looks at bits the thread part does not reach):
+    //   write  pad(t + q S)        = pad(t) + q WS,   S = L / RHO,  WS = S + ((S >> K) << LOGR'),  K = LR' + LOGR'
+    //   read   pad(base + q R')    = pad(base) + q R'
+    // so each thread needs ONE write and ONE read address per u (plus the buffer offset) and every access is
+    // base + immediate.  Written this way on purpose: left as pad(t + q S) hipcc materialises one address register per
+    // slot, keeps the sets of all steps and columns alive and spills them (64 of them in the 8192-point column pass).
     template <int J, int SEQ0>
     static __device__ __forceinline__ void exchange(float2 (&v)[B][V], float2* lds, int tid) {
         constexpr int LR = St::lr(J), NU = St::nu(J), RHO = 1 << LR;
         constexpr int LRn = St::lr(J + 1), NUn = St::nu(J + 1), RHOn = 1 << LRn, LOGRn = St::logR(J + 1);
+        constexpr int SW = 1 << (LOGL - LR), K = LRn + LOGRn;
+        constexpr int WS = LOGRn < 5 ? SW + ((SW >> K) << LOGRn) : SW;
+        int wbase[NU], rbase[NUn];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) wbase[u] = pad<J>(tid + u * T);
+#pragma unroll
+        for (int u = 0; u < NUn; ++u) {
+            const int bid = tid + u * T;
+            rbase[u] = pad<J>(((bid >> LOGRn) << (LRn + LOGRn)) + (bid & ((1 << LOGRn) - 1)));
+        }
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             const int slot = SEQ0 + J * B + b;
@@ -343,15 +458,12 @@ struct FftCore {
 #pragma unroll
             for (int u = 0; u < NU; ++u)
 #pragma unroll
-                for (int q = 0; q < RHO; ++q) buf[pad<J>((tid + u * T) + (q << (LOGL - LR)))] = v[b][u * RHO + q];
+                for (int q = 0; q < RHO; ++q) buf[wbase[u] + q * WS] = v[b][u * RHO + q];
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < NUn; ++u) {
-                const int bid = tid + u * T;
-                const int base = ((bid >> LOGRn) << (LRn + LOGRn)) + (bid & ((1 << LOGRn) - 1));
+            for (int u = 0; u < NUn; ++u)
 #pragma unroll
-                for (int q = 0; q < RHOn; ++q) v[b][u * RHOn + q] = buf[pad<J>(base + (q << LOGRn))];
-            }
+                for (int q = 0; q < RHOn; ++q) v[b][u * RHOn + q] = buf[rbase[u] + (q << LOGRn)];
         }
     }
 

@@ -45,7 +45,8 @@ struct RowArgs {
     int mm_rows, mm_cols;
     int M;              // number of rows to transform
     size_t pstride;     // rows4 kernels: panel stride of the panel-major spectrum, in float2 elements
-    int half;           // rows4 packed kernels: half (Hermitian) spectrum, N/8 + 1 panels
+    int half;           // rows4 packed kernels: half (Hermitian) spectrum, N/8 panels
+    int num_cu;         // rows4 persistent kernels: CUs of the device
     RowBatch batch;     // rows4 packed kernels: several images per launch
 };
 
@@ -97,7 +98,8 @@ hipError_t launch_cols(int logm, int mode, ColKind kind, const ColArgs& a, const
 // fast-mode passes on the panel-major intermediate (fdr_panel.hip); tw_fwd = forward table
 // rows4: (ROW_IN_REAL -> ROW_OUT_COMPLEX[panel]) forward, (ROW_IN_COMPLEX[panel] -> ROW_OUT_REAL_MINMAX) inverse
 hipError_t launch_rows4(int logl, RowIn in, RowOut out, const RowArgs& a, const float2* tw_fwd, hipStream_t s);
-int rows4_minmax_partials(int logl, int M);
+// min/max partials pass C' writes per image when `nimg` images share a launch on a device with num_cu CUs
+int rows4_minmax_partials(int logl, int M, int num_cu, int nimg);
 // fused C'+E: geometry (returns 0 when this shape cannot run fused: R row groups per thread group, nwg workgroups)
 int rows4_fused_geometry(int logl, int M, int num_cu, int* R, int* nwg);
 hipError_t launch_rows4_inv_norm(int logl, int R, int nwg, const RowArgs& a, const NormArgs& na, const float2* tw_fwd, hipStream_t s);

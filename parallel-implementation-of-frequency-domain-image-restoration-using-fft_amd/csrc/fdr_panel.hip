@@ -181,6 +181,163 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Persistent form of pass A (rows of 2048 points and more: one thread group = one workgroup).  A launch of the kernel
+// above runs in lockstep -- every workgroup loads, then every workgroup transforms, then every workgroup stores -- so
+// HBM idles while the CUs compute and the CUs idle while HBM streams (measured: 18 us per round of 512 workgroups at
+// 4096^2 = 10.9 us of memory time + 7 us of transform, nothing overlapped).  Here a workgroup walks over its row groups
+// and requests the NEXT group's four image rows (4 V floats per thread) before it transforms the current one; the
+// stores of the current group drain behind the next group's transform.  The prefetch is unconditional (clamped
+// addresses, collapsed onto one element when there is no next group; zero padding is applied when the values are
+// packed): a conditional load would make the compiler wait for it right away (lesson 1).
+//   LOGV = 3: 8 values per thread, T = L/8 threads, two workgroups per CU at 4096 points (2 x 74 KB of LDS)
+//   LOGV = 4: 16 values per thread, T = L/16 threads: 8192-point rows as ONE 512-thread workgroup per CU with a
+//             256-register budget (the 8-value form needs 1024 threads at 128 registers and cannot hold a prefetch)
+// ---------------------------------------------------------------------------------------------
+#ifndef FDR_ROWS12_LOGV
+#define FDR_ROWS12_LOGV 3  // values per thread (log2) of the persistent row passes for rows of 2048 / 4096 points
+#endif
+template <int LOGL, int LOGV>
+struct RowsPersGeom {
+    using St = Steps<LOGL, LOGV>;
+    static constexpr int T = St::T;
+    static_assert(T >= 256, "one thread group per workgroup");
+    static constexpr int THREADS = T;
+    static constexpr int LDS_BYTES = 2 * St::BUF * 8;
+    static constexpr int BY_LDS = (160 * 1024) / LDS_BYTES;
+    static constexpr int BY_REGS = (LOGV == 3 ? 4 : 2) * 256 / THREADS;  // 128 registers (V = 8) or 256 (V = 16) per lane
+    static constexpr int WG_PER_CU = BY_LDS < BY_REGS ? (BY_LDS < 1 ? 1 : BY_LDS) : (BY_REGS < 1 ? 1 : BY_REGS);
+    static constexpr int WAVES_PER_SIMD = WG_PER_CU * THREADS / 256;
+};
+
+template <int LOGL, int LOGV, bool HALF, bool INTERIOR>
+__global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<LOGL, LOGV>::WAVES_PER_SIMD)) void fft_rows4_fwd_pers_kernel(
+    const RowArgs a, const float2* __restrict__ tw_fwd, const int ngroups, const int total) {
+    using St = Steps<LOGL, LOGV>;
+    constexpr int T = St::T, L = St::L, V = St::V;
+    using Core = FftCore<LOGL, 2, 2, PolicyFast, LOGV>;
+    __shared__ float2 lds[2 * St::BUF];
+    const int tid = threadIdx.x;
+    const int nimg = a.batch.nimg > 1 ? a.batch.nimg : 1;
+
+    typename Core::Bases bases;
+    Core::init_bases(bases, tw_fwd, tid);
+
+    // group gi = (image, 4-row group); advanced by scalar add / subtract (no division on the vector unit)
+    int gi = blockIdx.x;
+    if (gi >= total) return;
+    int img = 0, grp = gi;
+    while (grp >= ngroups) { grp -= ngroups; ++img; }
+    auto src_of = [&](int im) -> const float* { return nimg > 1 ? pick4(a.batch.src_real, im) : a.src_real; };
+    auto dst_of = [&](int im) -> float2* { return nimg > 1 ? pick4(a.batch.spec, im) : a.dst_c; };
+
+    // four image rows of group `g` of image `im`: unconditional loads from clamped coordinates; scale = 0 collapses
+    // every address onto element 0 of the image (no next group)
+    float x[4][V];
+    auto request = [&](const float* __restrict__ src, int g, unsigned scale) {
+        const int r0 = g * 4;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            int r = r0 + b;
+            if (!INTERIOR) r = r < a.src_rows ? r : a.src_rows - 1;
+            const float* __restrict__ row = src + (size_t)r * (size_t)a.src_stride * scale;
+#pragma unroll
+            for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHO0; ++q) {
+                    const int s = u * Core::RHO0 + q;
+                    unsigned n = (unsigned)Core::in_index(tid, u, q);
+                    if (!INTERIOR) n = n < (unsigned)a.src_cols ? n : (unsigned)a.src_cols - 1u;
+                    x[b][s] = __builtin_nontemporal_load(row + n * scale);  // the image is read exactly once
+                }
+        }
+    };
+    request(src_of(img), grp, 1u);
+
+    while (true) {
+        // pack: z[0] = rows 0 + i 1, z[1] = rows 2 + i 3 (zero padding applied here)
+        float2 z[2][V];
+        {
+            const int r0 = grp * 4;
+#pragma unroll
+            for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHO0; ++q) {
+                    const int s = u * Core::RHO0 + q;
+                    float v0 = x[0][s], v1 = x[1][s], v2 = x[2][s], v3 = x[3][s];
+                    if (!INTERIOR) {
+                        const bool cok = Core::in_index(tid, u, q) < a.src_cols;
+                        v0 = (cok && r0 + 0 < a.src_rows) ? v0 : 0.f;
+                        v1 = (cok && r0 + 1 < a.src_rows) ? v1 : 0.f;
+                        v2 = (cok && r0 + 2 < a.src_rows) ? v2 : 0.f;
+                        v3 = (cok && r0 + 3 < a.src_rows) ? v3 : 0.f;
+                    }
+                    z[0][s] = make_float2(v0, v1);
+                    z[1][s] = make_float2(v2, v3);
+                }
+        }
+        // next group of this workgroup
+        const int gn = gi + (int)gridDim.x;
+        const bool more = gn < total;
+        int nimg_i = img, ngrp = grp;
+        if (more) {
+            ngrp += (int)gridDim.x;
+            while (ngrp >= ngroups) { ngrp -= ngroups; ++nimg_i; }
+        }
+        request(src_of(more ? nimg_i : img), more ? ngrp : 0, more ? 1u : 0u);
+
+        Core::template run<0, false>(z, lds, tw_fwd, bases, tid);
+
+        // Separate the two real rows of each packed transform and store all four spectra panel-major: both packed
+        // spectra go to LDS in natural order, then a quad of lanes owns one 128-byte line (4 rows x 4 columns of a
+        // panel): lane j of the quad builds row j's four columns (see fft_rows4_fwd_packed_kernel).
+        constexpr int SEQ1 = Core::SLOTS;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float2* buf = lds + ((SEQ1 + b) & 1) * St::BUF;
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) buf[Core::out_index(tid, u, q)] = z[b][u * Core::RHOL + q];
+        }
+        __syncthreads();
+        {
+            float2* __restrict__ dst = dst_of(img);
+            const int r0 = grp * 4;
+            // (opaque copy of the thread index: the LDS and panel addresses below are loop invariant, and hoisted out of
+            // the group loop they would occupy ~25 registers for the whole kernel -- recomputing them costs a few adds)
+            int tq = tid;
+            asm volatile("" : "+v"(tq));
+            const int j = tq & 3;                                            // row inside the 4-row group
+            const float2* buf = lds + ((SEQ1 + (j >> 1)) & 1) * St::BUF;     // packed pair holding row j
+            const bool odd = (j & 1) != 0;                                   // row b of the pair (else row a)
+            constexpr int NIT = (HALF ? L / 8 : L / 4) / (T / 4);            // panels per lane
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int c = (tq >> 2) + (T / 4) * i;  // panel
+                const int n0 = c * 4;
+                float2 o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float2 zn = buf[n0 + k];
+                    const float2 zm = buf[(L - n0 - k) & (L - 1)];
+                    o[k] = odd ? make_float2(0.5f * (zn.y + zm.y), 0.5f * (zm.x - zn.x))
+                               : make_float2(0.5f * (zn.x + zm.x), 0.5f * (zn.y - zm.y));
+                }
+                if (HALF && n0 == 0) {  // packed column: (X[0], X[N/2]), both real: Re/Im of Z[0] and Z[N/2]
+                    const float2 z0 = buf[0], zq = buf[L / 2];
+                    o[0] = odd ? make_float2(z0.y, zq.y) : make_float2(z0.x, zq.x);
+                }
+                store4(dst + (size_t)c * a.pstride + (size_t)(r0 + j) * 4, o[0], o[1], o[2], o[3]);
+                asm volatile("" ::: "memory");  // one panel at a time: keeps the LDS reads of later panels from piling up in registers
+            }
+        }
+        if (!more) break;
+        __syncthreads();  // the separation's reads are done before the next transform's first exchange writes
+        gi = gn; img = nimg_i; grp = ngrp;
+    }
+}
+
 // Four Hermitian row spectra (rows rr .. rr+3) rebuilt from the panel-major (half) spectrum and packed two rows per
 // complex transform, in two steps so that the loads of the NEXT row group can be issued (into y) before the values
 // are touched:  rows4_load_raw -> y[row][slot] (first-step operand order, stored column of slot s),
@@ -192,7 +349,7 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
 // selects; only lane tid = 0 differs (n = 0: DC, n = L/2: Nyquist -- both live in the packed column 0) and is
 // patched separately.  Addresses: one uniform base per slot + two per-lane 32-bit offsets (direct / mirrored).
 template <int LOGL, bool HALF, class Core>
-__device__ __forceinline__ void rows4_load_raw(const RowArgs& a, int rr, int tid, float2 (&y)[4][8]) {
+__device__ __forceinline__ void rows4_load_raw(const RowArgs& a, int rr, int tid, float2 (&y)[4][Core::V], unsigned scale = 1u) {
     constexpr int L = Steps<LOGL>::L;
     if constexpr (!HALF || LOGL < 5) {  // (half-spectrum plans need N >= 32; smaller instantiations are never launched)
 #pragma unroll
@@ -201,23 +358,24 @@ __device__ __forceinline__ void rows4_load_raw(const RowArgs& a, int rr, int tid
             for (int q = 0; q < Core::RHO0; ++q) {
                 const int s = u * Core::RHO0 + q;
                 const int n = Core::in_index(tid, u, q);
-                const float2* p = a.src_c + (size_t)(n >> 2) * a.pstride + (size_t)rr * 4 + (n & 3);
+                const float2* p = a.src_c + ((size_t)(n >> 2) * a.pstride + (size_t)rr * 4 + (n & 3)) * scale;
                 y[0][s] = p[0]; y[1][s] = p[4]; y[2][s] = p[8]; y[3][s] = p[12];
             }
     } else {
         static_assert(Core::RHO0 >= 2 && Core::LOGR0 >= 2, "n = t + q Q with Q a multiple of 4");
-        const unsigned ps = (unsigned)a.pstride;
+        const unsigned ps = (unsigned)a.pstride * scale;  // scale = 0: every address collapses onto rows 0..3 of panel 0 (a prefetch with nothing to fetch)
+        rr = (int)((unsigned)rr * scale);
 #pragma unroll
         for (int u = 0; u < Core::NU0; ++u) {
             const unsigned t = (unsigned)(tid + u * Core::T);        // n = t + q Q,  Q = 2^LOGR0 (a multiple of 4)
             const unsigned ta = t >> 2, tb = t & 3u;
             // direct half: stored column t + qQ -> panel qQ/4 + ta, column tb
-            const unsigned off_d = ta * ps + tb + (unsigned)rr * 4u;
+            const unsigned off_d = ta * ps + tb * scale + (unsigned)rr * 4u;
             // mirrored half: stored column (RHO0 - q) Q - t -> panel (RHO0-q)Q/4 - ta - (tb != 0), column (4 - tb) & 3;
             // relative to q = RHO0/2 (panel L/8): the lane part is folded into an offset from panel (L/8 - T NU0/4 ... ) >= 0
             constexpr unsigned PMID = (unsigned)(L / 8);              // panel of column L/2 (one past the stored panels)
             const unsigned pm = PMID - ta - (tb != 0u ? 1u : 0u);     // panel of the mirrored column at q = RHO0/2
-            const unsigned off_m = pm * ps + ((4u - tb) & 3u) + (unsigned)rr * 4u;
+            const unsigned off_m = pm * ps + ((4u - tb) & 3u) * scale + (unsigned)rr * 4u;
             // n = L/2 (lane t = 0 of the q = RHO0/2 slot): the Nyquist value rides in column 0 of panel 0
             const unsigned off_n = (u == 0 && t == 0u) ? (unsigned)rr * 4u : off_m;
 #pragma unroll
@@ -241,7 +399,7 @@ __device__ __forceinline__ void rows4_load_raw(const RowArgs& a, int rr, int tid
     }
 }
 template <int LOGL, bool HALF, class Core>
-__device__ __forceinline__ void rows4_pack(int tid, const float2 (&y)[4][8], float2 (&z)[2][8]) {
+__device__ __forceinline__ void rows4_pack(int tid, const float2 (&y)[4][Core::V], float2 (&z)[2][Core::V]) {
 #pragma unroll
     for (int u = 0; u < Core::NU0; ++u)
 #pragma unroll
@@ -339,6 +497,110 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_pa
         }
     }
     block_minmax_store(mn, mx, a.mm_part, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent form of pass C' (see fft_rows4_fwd_pers_kernel): the raw half spectrum of the NEXT 4-row group is
+// requested (rows4_load_raw into y) before the current group is transformed and stored.  grid (workgroups, images):
+// a workgroup stays inside one image, so it writes ONE (min, max) partial for all its groups.
+// ---------------------------------------------------------------------------------------------
+template <int LOGL, int LOGV, bool HALF>
+__global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<LOGL, LOGV>::WAVES_PER_SIMD)) void fft_rows4_inv_pers_kernel(
+    const RowArgs a0, const float2* __restrict__ tw_fwd, const int ngroups) {
+    RowArgs a = a0;
+    if (a0.batch.nimg > 1) {  // blockIdx.y = image
+        a.src_c = pick4(a0.batch.spec, blockIdx.y);
+        a.dst_real = pick4(a0.batch.raw, blockIdx.y);
+        a.mm_part = pick4(a0.batch.mm_part, blockIdx.y);
+    }
+    using St = Steps<LOGL, LOGV>;
+    constexpr int T = St::T, L = St::L, V = St::V;
+    using Core = FftCore<LOGL, 2, 2, PolicyFast, LOGV>;
+    __shared__ float2 lds[2 * St::BUF];
+    const int tid = threadIdx.x;
+
+    typename Core::Bases bases;
+    Core::init_bases(bases, tw_fwd, tid);
+
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    int grp = blockIdx.x;  // (the grid never exceeds the number of groups)
+    float2 y[4][V];
+    rows4_load_raw<LOGL, HALF, Core>(a, grp * 4, tid, y, 1u);
+    while (true) {
+        float2 z[2][V];
+        rows4_pack<LOGL, HALF, Core>(tid, y, z);
+        const int gn = grp + (int)gridDim.x;
+        const bool more = gn < ngroups;
+        {
+            int tl = tid;  // opaque copy: the per-lane panel offsets are recomputed per group instead of living in ~16 registers
+            asm volatile("" : "+v"(tl));
+            rows4_load_raw<LOGL, HALF, Core>(a, more ? gn * 4 : 0, tl, y, more ? 1u : 0u);
+        }
+
+        Core::template run<0, true>(z, lds, tw_fwd, bases, tid);
+
+        {
+            const int r0 = grp * 4;
+            int tq = tid;  // opaque copy: keeps the store addresses from being hoisted out of the group loop
+            asm volatile("" : "+v"(tq));
+            float* o0 = a.dst_real + (size_t)r0 * L + tq;
+            float* o1 = o0 + L;
+            float* o2 = o1 + L;
+            float* o3 = o2 + L;
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int s = u * Core::RHOL + q;
+                    const int c = u * T + (q << Core::LOGOUT);
+                    o0[c] = z[0][s].x; o1[c] = z[0][s].y; o2[c] = z[1][s].x; o3[c] = z[1][s].y;
+                }
+            if (r0 + 3 < a.mm_rows && a.mm_cols >= L) {  // whole group counted (always, with FDR_NORM_PADDED)
+#pragma unroll
+                for (int s = 0; s < V; ++s) {
+                    mn = fminf(fminf(mn, z[0][s].x), fminf(z[0][s].y, fminf(z[1][s].x, z[1][s].y)));
+                    mx = fmaxf(fmaxf(mx, z[0][s].x), fmaxf(z[0][s].y, fmaxf(z[1][s].x, z[1][s].y)));
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                    for (int q = 0; q < Core::RHOL; ++q) {
+                        const int s = u * Core::RHOL + q;
+                        const int n = Core::out_index(tq, u, q);
+                        const float r[4] = {z[0][s].x, z[0][s].y, z[1][s].x, z[1][s].y};
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            if (r0 + b < a.mm_rows && n < a.mm_cols) {
+                                mn = fminf(mn, r[b]);
+                                mx = fmaxf(mx, r[b]);
+                            }
+                    }
+            }
+        }
+        if (!more) break;
+        grp = gn;
+        // (no barrier needed here: the last exchange of the transform ended with every thread's reads, and the next
+        // transform's first exchange writes the OTHER buffer when the slot count per run is odd -- it is not in
+        // general, so keep the two runs apart)
+        __syncthreads();
+    }
+    block_minmax_store(mn, mx, a.mm_part, (int)blockIdx.x);
+}
+
+// persistent pass C': workgroups per image (the number of min/max partials the pass writes for one image)
+template <int LOGL>
+static int rows4_inv_pers_grid(int M, int num_cu, int nimg) {
+    if constexpr (LOGL >= 11) {
+        constexpr int LOGV = LOGL >= 13 ? 4 : (LOGL == 12 ? FDR_ROWS12_LOGV : 3);
+        using PG = RowsPersGeom<LOGL, LOGV>;
+        const int groups = (M + 3) / 4;
+        int g = (num_cu > 0 ? num_cu : 256) * PG::WG_PER_CU / (nimg > 1 ? nimg : 1);
+        if (g < 1) g = 1;
+        return g > groups ? groups : g;
+    } else {
+        return 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -582,15 +844,48 @@ __global__ __launch_bounds__(256) void normalize_fixup_kernel(const RowArgs a, c
     if (threadIdx.x == 0) na.fallback[w] = 0u;
 }
 
+#ifndef FDR_ROWS_PERSISTENT
+#define FDR_ROWS_PERSISTENT 1
+#endif
 template <int LOGL>
 static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const float2* tw, hipStream_t s) {
     using Geo = Rows4PackGeom<LOGL>;
     const int groups = (a.M + 3) / 4;
-    const dim3 grid((groups + Geo::G - 1) / Geo::G, a.batch.nimg > 1 ? a.batch.nimg : 1), block(Geo::THREADS);
+    const int nimg = a.batch.nimg > 1 ? a.batch.nimg : 1;
+    const dim3 grid((groups + Geo::G - 1) / Geo::G, nimg), block(Geo::THREADS);
     if (in == ROW_IN_REAL && out == ROW_OUT_COMPLEX) {
+        if constexpr (LOGL >= 11 && FDR_ROWS_PERSISTENT) {
+            if ((a.M & 3) == 0 && a.src_rows > 0 && a.src_cols > 0) {  // persistent, prefetching form
+                constexpr int LOGV = LOGL >= 13 ? 4 : (LOGL == 12 ? FDR_ROWS12_LOGV : 3);
+                using PG = RowsPersGeom<LOGL, LOGV>;
+                const int total = groups * nimg;
+                int g = (a.num_cu > 0 ? a.num_cu : 256) * PG::WG_PER_CU;
+                if (g > total) g = total;
+                const bool interior = a.src_rows >= a.M && a.src_cols >= (1 << LOGL);
+                const dim3 pgrid(g), pblock(PG::THREADS);
+                if (a.half) {
+                    if (interior) hipLaunchKernelGGL((fft_rows4_fwd_pers_kernel<LOGL, LOGV, true, true>), pgrid, pblock, 0, s, a, tw, groups, total);
+                    else hipLaunchKernelGGL((fft_rows4_fwd_pers_kernel<LOGL, LOGV, true, false>), pgrid, pblock, 0, s, a, tw, groups, total);
+                } else {
+                    if (interior) hipLaunchKernelGGL((fft_rows4_fwd_pers_kernel<LOGL, LOGV, false, true>), pgrid, pblock, 0, s, a, tw, groups, total);
+                    else hipLaunchKernelGGL((fft_rows4_fwd_pers_kernel<LOGL, LOGV, false, false>), pgrid, pblock, 0, s, a, tw, groups, total);
+                }
+                return hipGetLastError();
+            }
+        }
         if (a.half) hipLaunchKernelGGL((fft_rows4_fwd_packed_kernel<LOGL, true>), grid, block, 0, s, a, tw);
         else hipLaunchKernelGGL((fft_rows4_fwd_packed_kernel<LOGL, false>), grid, block, 0, s, a, tw);
     } else if (in == ROW_IN_COMPLEX && out == ROW_OUT_REAL_MINMAX) {
+        if constexpr (LOGL >= 11 && FDR_ROWS_PERSISTENT) {
+            if ((a.M & 3) == 0) {
+                constexpr int LOGV = LOGL >= 13 ? 4 : (LOGL == 12 ? FDR_ROWS12_LOGV : 3);
+                using PG = RowsPersGeom<LOGL, LOGV>;
+                const dim3 pgrid(rows4_inv_pers_grid<LOGL>(a.M, a.num_cu, nimg), nimg), pblock(PG::THREADS);
+                if (a.half) hipLaunchKernelGGL((fft_rows4_inv_pers_kernel<LOGL, LOGV, true>), pgrid, pblock, 0, s, a, tw, groups);
+                else hipLaunchKernelGGL((fft_rows4_inv_pers_kernel<LOGL, LOGV, false>), pgrid, pblock, 0, s, a, tw, groups);
+                return hipGetLastError();
+            }
+        }
         if (a.half) hipLaunchKernelGGL((fft_rows4_inv_packed_kernel<LOGL, true>), grid, block, 0, s, a, tw);
         else hipLaunchKernelGGL((fft_rows4_inv_packed_kernel<LOGL, false>), grid, block, 0, s, a, tw);
     } else {
@@ -600,7 +895,12 @@ static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const f
 }
 
 template <int LOGL>
-static int rows4_partials_t(int M) { return ((M + 3) / 4 + Rows4PackGeom<LOGL>::G - 1) / Rows4PackGeom<LOGL>::G; }
+static int rows4_partials_t(int M, int num_cu, int nimg) {
+    if constexpr (LOGL >= 11 && FDR_ROWS_PERSISTENT) {
+        if ((M & 3) == 0) return rows4_inv_pers_grid<LOGL>(M, num_cu, nimg);
+    }
+    return ((M + 3) / 4 + Rows4PackGeom<LOGL>::G - 1) / Rows4PackGeom<LOGL>::G;
+}
 
 #define FDR_DISPATCH_LOG(var, expr)                                                     \
     switch (var) {                                                                      \
@@ -623,8 +923,8 @@ hipError_t launch_rows4(int logl, RowIn in, RowOut out, const RowArgs& a, const 
     return hipErrorInvalidValue;
 }
 
-int rows4_minmax_partials(int logl, int M) {
-    FDR_DISPATCH_LOG(logl, rows4_partials_t<LG>(M));
+int rows4_minmax_partials(int logl, int M, int num_cu, int nimg) {
+    FDR_DISPATCH_LOG(logl, rows4_partials_t<LG>(M, num_cu, nimg));
     return 0;
 }
 
@@ -1025,6 +1325,12 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::PIPE_WAV
 // 8192-point columns: 512 threads, one workgroup per CU, no spills (the radix-8 kernel needs 1024 threads at 128
 // VGPRs there).  One tile per workgroup; the tile sequence runs over the images of the launch.
 // ---------------------------------------------------------------------------------------------
+#ifndef FDR_WPIECE
+#define FDR_WPIECE 4
+#endif
+#ifndef FDR_COLS12_PACKED
+#define FDR_COLS12_PACKED 1
+#endif
 template <int LOGM>
 struct Panel16Geom {
     static constexpr int T = Steps<LOGM, 4>::T;
@@ -1040,7 +1346,7 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
     const int npanels, const int ntiles, const int packed0) {
     using St = Steps<LOGM, 4>;
     constexpr int G = Panel16Geom<LOGM>::G, T = St::T, M = St::L, V = 16;
-    using Core = FftCore<LOGM, 4, 2, typename std::conditional<LOGM == 12, PolicyFastScalar, PolicyFast>::type, 4>;  // see PolicyFastScalar
+    using Core = FftCore<LOGM, 4, 2, typename std::conditional<(LOGM == 12 && !FDR_COLS12_PACKED), PolicyFastScalar, PolicyFast>::type, 4>;  // see PolicyFastScalar
     __shared__ float2 lds[G * 2 * St::BUF];
     const int g = G == 1 ? 0 : (int)(threadIdx.x >> St::LOGT);
     const int tid = threadIdx.x & (T - 1);
@@ -1076,15 +1382,20 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
         float2* bufc = grp_lds + (SEQ & 1) * St::BUF;
         float2* bufs = grp_lds + ((SEQ + 1) & 1) * St::BUF;
         __syncthreads();
+        // (once per image, on one workgroup: kept cheap in REGISTERS, not in time -- the filter values go to LDS two at
+        // a time behind compiler barriers and every slot is finished before the next one starts, so this path adds
+        // nothing to the pressure of the common one)
 #pragma unroll
         for (int u = 0; u < Core::NUL; ++u)
 #pragma unroll
-            for (int q = 0; q < Core::RHOL; ++q) {
-                const int s = u * Core::RHOL + q;
-                const int k = Core::out_index(tid, u, q);
-                bufc[k] = v[0][s];
-                bufs[k] = tfilt[loff - (unsigned)tid * 4u + (unsigned)k * 4u];  // (read back below: no registers held)
-            }
+            for (int q = 0; q < Core::RHOL; ++q) bufc[Core::out_index(tid, u, q)] = v[0][u * Core::RHOL + q];
+#pragma unroll
+        for (int s = 0; s < V; s += 2) {
+            const int k0 = Core::out_index(tid, s / Core::RHOL, s % Core::RHOL), k1 = Core::out_index(tid, (s + 1) / Core::RHOL, (s + 1) % Core::RHOL);
+            const float2 f0 = tfilt[loff - (unsigned)tid * 4u + (unsigned)k0 * 4u], f1 = tfilt[loff - (unsigned)tid * 4u + (unsigned)k1 * 4u];
+            bufs[k0] = f0; bufs[k1] = f1;
+            asm volatile("" ::: "memory");
+        }
         __syncthreads();
         if (g == 0) {
 #pragma unroll
@@ -1103,6 +1414,7 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
                     else { a0 = make_float2(sm.x, -sm.y); an = make_float2(sl_s.x, -sl_s.y); }
                     const float2 z0 = cmul_fma(f0, a0), zn = cmul_fma(fn, an);
                     v[0][s] = make_float2(z0.x - zn.y, z0.y + zn.x);
+                    asm volatile("" ::: "memory");
                 }
         }
         __syncthreads();  // both buffers were read above
@@ -1112,7 +1424,7 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
         // W in pieces of PC slots, the next piece requested before the current one is used.  (Measured: requesting the
         // first pieces before the forward transform costs 27 spilled registers and 5 us; the compiler barriers keep
         // hipcc from hoisting all 32 loads to the top.)
-        constexpr int PC = 4;  // slots per piece: 32 VGPRs, two pieces in flight
+        constexpr int PC = FDR_WPIECE;  // slots per piece: 8 VGPRs per slot, two pieces in flight
         auto wload = [&](int h, float2 (&w)[PC][4]) {
 #pragma unroll
             for (int i = 0; i < PC; ++i) {
@@ -1145,11 +1457,17 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
         }
     }
     FDR_STAMP(pb, wgid, 4);
-    if constexpr (Core::RHOL != Core::RHO0) {
-        redistribute<LOGM, Core, SEQ>(v, grp_lds, tid);
-        Core::template run<SEQ + 4, true>(v, grp_lds, tw_fwd, bases, tid);
-    } else {
-        Core::template run<SEQ, true>(v, grp_lds, tw_fwd, bases, tid);
+    {
+        // opaque copy of the thread index: the inverse transform's LDS addresses equal the forward transform's, and as
+        // common subexpressions they would stay alive across the filter phase, where register pressure peaks
+        int ti = tid;
+        asm volatile("" : "+v"(ti));
+        if constexpr (Core::RHOL != Core::RHO0) {
+            redistribute<LOGM, Core, SEQ>(v, grp_lds, ti);
+            Core::template run<SEQ + 4, true>(v, grp_lds, tw_fwd, bases, ti);
+        } else {
+            Core::template run<SEQ, true>(v, grp_lds, tw_fwd, bases, ti);
+        }
     }
     FDR_STAMP(pb, wgid, 5);
     if (active) tile_store<Core>(data, loff, v);

@@ -312,7 +312,7 @@ def test_phase_times_and_batch_run(fdr, oracle):
             ref_sum += float(q.wiener(oracle.synth_image(0x5EED0005, i * 65536, 65536).reshape(256, 256)).astype(np.float64).sum())
     assert abs(sum(st2["checksum"]) - ref_sum) < 1e-3, (sum(st2["checksum"]), ref_sum)
     with pytest.raises(fdr.FdrError):
-        fdr.batch_run([0, 99], 128, 256, 2, psf=psf, imgs=imgs[:2, :100, :200])  # device ordinal out of range
+        fdr.batch_run([0, 99], 128, 256, 2, rows=100, cols=200, psf=psf, imgs=imgs[:2])  # device ordinal out of range
     with pytest.raises(fdr.FdrError):
         fdr.batch_run([], 128, 256, 2, psf=psf)
 
