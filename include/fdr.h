@@ -55,6 +55,11 @@ extern "C" {
                                     faster (measured: DESIGN.md section 5).  The wait is bounded (FDR_OPT_FUSED_SPIN_LIMIT);
                                     a workgroup whose wait runs out writes raw rows that a fix-up launch normalises.      */
 
+#define FDR_FLAG_TABLES_ONLY 1024u /* twiddle tables and min/max scratch only, no M x N workspaces: a plan for the slab
+                                      primitives (fdr_slab_*) of the single-image multi-GPU mode, where every rank
+                                      holds only its rows of the image; fdr_wiener_* / fdr_fft2d_* / fdr_set_psf*
+                                      return FDR_ERR_STATE on such a plan                                          */
+
 #define FDR_FLAG_ANY_SIZE 512u /* accept plan dimensions that are not powers of two: such a dimension is transformed by
                                   the O(n^2) DFT of fft_serial::dft_naive_inplace (fft/fft_serial.cpp:71-87), as
                                   transform_row_inplace dispatches (:100-101) when wienerDeblur_myfft pads to
@@ -243,6 +248,30 @@ typedef struct fdr_batch_stats {
     double mpixels_per_s;                  /* images_done * rows * cols / wall_ms */
 } fdr_batch_stats;
 int fdr_batch_run(const fdr_batch_desc* desc, fdr_batch_stats* stats);
+
+/* -- single-image multi-GPU mode: the reference's MPI variant splits ONE image into row slabs and
+ *    transposes through MPI_Alltoallv (fft/fft_mpi.cpp:89-100 distribution, :170-279 distributed transpose, :284-307 the
+ *    2-D driver rows -> transpose -> rows -> transpose).  These are the per-rank device steps of that scheme; the exchange
+ *    itself belongs to the caller's communicator (RCCL all-to-all in ..._amd/slab.py).  All asynchronous on `stream`,
+ *    device pointers only; `plan` supplies the twiddle tables (and the arithmetic mode) for dimensions M and N.
+ *      pad       : real rows (valid_rows x valid_cols, row stride src_stride) -> rows x N complex, zero padded
+ *                  (copyMakeBorder + merge of fft/fft_mpi.cpp:357-366, for the rows this rank owns)
+ *      rows_fft  : `rows` contiguous transforms of length N (dim 0) or M (dim 1), in place, unscaled   (:291-294, :301-304)
+ *      pack      : column blocks of a rows x ld array, block p = columns [displs[p], displs[p] + counts[p]) stored
+ *                  rows x counts[p], blocks in rank order: the send buffer of :118-135; elem_size 4 (real) or 8 (complex)
+ *      transpose : dense rows x cols -> cols x rows, elem_size 4 or 8                                   (:154-166)
+ *      wiener    : G <- Wiener quotient of G against H, pointwise, with the plan's mode and K given     (fft_serial.cpp:186-224)
+ *      real      : real part of `count` complex values
+ *      minmax    : {min, max} of the window [0, mm_rows) x [0, mm_cols) of a real rows x ld plane into d_mm[2]
+ *      normalize : cv::normalize(0, 1, MINMAX) with the given {min, max}, cropped to rows x cols         (fft_serial.cpp:246) */
+int fdr_slab_pad_dev(const float* d_src, int valid_rows, int valid_cols, int src_stride, float* d_dst_complex, int rows, int N, void* stream);
+int fdr_slab_rows_fft_dev(fdr_plan* plan, float* d_complex, int rows, int dim, int inverse, void* stream);
+int fdr_slab_pack_dev(const void* d_src, int rows, int ld, int parts, const int* counts, int elem_size, void* d_dst, void* stream);
+int fdr_slab_transpose_dev(const void* d_src, void* d_dst, int rows, int cols, int elem_size, void* stream);
+int fdr_slab_wiener_dev(fdr_plan* plan, float* d_g, const float* d_h, size_t count, float K, void* stream);
+int fdr_slab_real_dev(const float* d_complex, float* d_real, size_t count, void* stream);
+int fdr_slab_minmax_dev(fdr_plan* plan, const float* d_real, int rows, int ld, int mm_rows, int mm_cols, float* d_mm, void* stream);
+int fdr_slab_normalize_dev(const float* d_real, int ld, const float* d_mm, float* d_out, int rows, int cols, int out_stride, void* stream);
 
 #ifdef __cplusplus
 }

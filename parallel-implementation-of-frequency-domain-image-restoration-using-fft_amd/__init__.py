@@ -24,6 +24,7 @@ FLAG_SIMPLE_PATH = 1
 FLAG_FULL_SPECTRUM = 32
 FLAG_FUSED_NORM = 128
 FLAG_ANY_SIZE = 512
+FLAG_TABLES_ONLY = 1024
 NORM_PADDED = 1
 NORM_CROPPED = 0
 MAX_PASSES = 16
@@ -94,6 +95,14 @@ def _load():
     L.fdr_plan_set_option.argtypes = [vp, ci, ctypes.c_longlong]
     L.fdr_plan_phase_times.argtypes = [vp, _f32p, ci]
     L.fdr_batch_run.argtypes = [ctypes.POINTER(BatchDesc), ctypes.POINTER(BatchStats)]
+    L.fdr_slab_pad_dev.argtypes = [vp, ci, ci, ci, vp, ci, ci, vp]
+    L.fdr_slab_rows_fft_dev.argtypes = [vp, vp, ci, ci, ci, vp]
+    L.fdr_slab_pack_dev.argtypes = [vp, ci, ci, ci, ctypes.POINTER(ci), ci, vp, vp]
+    L.fdr_slab_transpose_dev.argtypes = [vp, vp, ci, ci, ci, vp]
+    L.fdr_slab_wiener_dev.argtypes = [vp, vp, vp, ctypes.c_size_t, cf, vp]
+    L.fdr_slab_real_dev.argtypes = [vp, vp, ctypes.c_size_t, vp]
+    L.fdr_slab_minmax_dev.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
+    L.fdr_slab_normalize_dev.argtypes = [vp, ci, vp, vp, ci, ci, ci, vp]
     L.fdr_plan_create.argtypes = [ci, ci, ci, ci, cu, ctypes.POINTER(vp)]
     L.fdr_plan_destroy.argtypes = [vp]
     L.fdr_plan_dims.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
@@ -125,7 +134,9 @@ def _load():
                  "fdr_wiener_f32", "fdr_wiener_f32_dev", "fdr_wiener_batch_f32_dev", "fdr_wiener_batch_f32", "fdr_wiener_batch_ptrs_f32", "fdr_host_alloc", "fdr_host_free",
                  "fdr_white_balance_u8", "fdr_white_balance_u8_dev", "fdr_plan_set_concurrency", "fdr_plan_set_batching",
                  "fdr_fft2d_c2c", "fdr_fft2d_c2c_dev", "fdr_fft1d_c2c", "fdr_dft_naive_c2c", "fdr_synth_image_dev", "fdr_plan_profile", "fdr_plan_pass_times",
-                 "fdr_optimal_dft_size", "fdr_plan_set_option", "fdr_plan_phase_times", "fdr_batch_run"):
+                 "fdr_optimal_dft_size", "fdr_plan_set_option", "fdr_plan_phase_times", "fdr_batch_run",
+                 "fdr_slab_pad_dev", "fdr_slab_rows_fft_dev", "fdr_slab_pack_dev", "fdr_slab_transpose_dev", "fdr_slab_wiener_dev",
+                 "fdr_slab_real_dev", "fdr_slab_minmax_dev", "fdr_slab_normalize_dev"):
         getattr(L, name).restype = ci
     return L
 
@@ -139,7 +150,9 @@ EXPORTED_SYMBOLS = (
     "fdr_host_alloc", "fdr_host_free", "fdr_white_balance_u8", "fdr_white_balance_u8_dev", "fdr_plan_set_concurrency",
     "fdr_plan_set_batching", "fdr_fft2d_c2c",
     "fdr_fft2d_c2c_dev", "fdr_fft1d_c2c", "fdr_dft_naive_c2c", "fdr_synth_image_dev", "fdr_plan_profile",
-    "fdr_plan_pass_times", "fdr_optimal_dft_size", "fdr_plan_set_option", "fdr_plan_phase_times", "fdr_batch_run")
+    "fdr_plan_pass_times", "fdr_optimal_dft_size", "fdr_plan_set_option", "fdr_plan_phase_times", "fdr_batch_run",
+    "fdr_slab_pad_dev", "fdr_slab_rows_fft_dev", "fdr_slab_pack_dev", "fdr_slab_transpose_dev", "fdr_slab_wiener_dev",
+    "fdr_slab_real_dev", "fdr_slab_minmax_dev", "fdr_slab_normalize_dev")
 
 
 def _check(rc):

@@ -55,6 +55,22 @@ class Comm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def allreduce_min(self, x):
+        if self.dist is None:
+            return float(x)
+        import torch
+        t = self._tensor([float(x)], torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return float(t.item())
+
+    def gather_objects(self, obj):
+        """list of every rank's picklable object on rank 0 (None elsewhere); plumbing for tests and result collection"""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world if self.rank == 0 else None
+        self.dist.gather_object(obj, out, dst=0)
+        return out
+
     def allreduce_sum(self, vals):
         if self.dist is None:
             return [float(v) for v in vals]

@@ -122,6 +122,7 @@ struct fdr_plan {
     unsigned flags = 0;
     bool simple = false;
     int num_cu = 256;
+    bool tables_only = false;  // FDR_FLAG_TABLES_ONLY: no workspaces, slab primitives only
     bool generic = false;  // FDR_FLAG_ANY_SIZE with a non-power-of-two dimension: naive DFT along that dimension
     float2 *naive_row = nullptr, *naive_col = nullptr;  // n x n tables of the non-power-of-two dimensions (length N / M)
     bool panel = false;
@@ -273,6 +274,7 @@ int dft2d_dev(fdr_plan* p, float2* d, float2* work2, bool inverse, hipStream_t s
 }
 
 int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int pstride, float K, hipStream_t s) {
+    if (p->tables_only) return fail(FDR_ERR_STATE, "fdr_set_psf: plan was created with FDR_FLAG_TABLES_ONLY (slab primitives only)");
     if (prows <= 0 || pcols <= 0 || pstride < pcols) return fail(FDR_ERR_ARG, "fdr_set_psf: bad PSF shape");
     if (prows > p->M || pcols > p->N)
         return fail(FDR_ERR_ARG, "fdr_set_psf: PSF larger than the padded image (copyMakeBorder would throw, fft_serial.cpp:168)");
@@ -443,6 +445,7 @@ int panel_stage_CE_batch(fdr_plan* p, fdr_plan::Slot* const* ws, int n, int rows
 }
 
 int check_image_args(fdr_plan* p, const float* d_img, int rows, int cols, int stride, float* d_out, int out_stride) {
+    if (p->tables_only) return fail(FDR_ERR_STATE, "fdr_wiener: plan was created with FDR_FLAG_TABLES_ONLY (slab primitives only)");
     if (!p->have_psf) return fail(FDR_ERR_STATE, "fdr_wiener: no PSF set on this plan (call fdr_set_psf* first)");
     if (!d_img || !d_out) return fail(FDR_ERR_ARG, "fdr_wiener: null image pointer");
     if (rows <= 0 || cols <= 0 || rows > p->M || cols > p->N || stride < cols || out_stride < cols)
@@ -589,12 +592,13 @@ static int plan_create_impl(fdr_plan* p, int device, int M, int N, int mode, uns
     } else {
         build_naive_table(M, t); if ((rc = upload(&p->naive_col, t)) != FDR_OK) return rc;
     }
-    if (hipMalloc((void**)&p->work, P * sizeof(float2)) != hipSuccess ||
-        hipMalloc((void**)&p->filt, P * sizeof(float2)) != hipSuccess ||
-        hipMalloc((void**)&p->raw, (size_t)M * N * sizeof(float)) != hipSuccess ||
+    p->tables_only = (flags & FDR_FLAG_TABLES_ONLY) != 0;
+    if ((!p->tables_only && (hipMalloc((void**)&p->work, P * sizeof(float2)) != hipSuccess ||
+                             hipMalloc((void**)&p->filt, P * sizeof(float2)) != hipSuccess ||
+                             hipMalloc((void**)&p->raw, (size_t)M * N * sizeof(float)) != hipSuccess)) ||
         hipMalloc((void**)&p->mm, 2 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&p->mm_part, (size_t)(p->mm_part_cap = (int)(((size_t)N + 255) / 256 * M + 8192)) * sizeof(float2)) != hipSuccess ||
-        (p->simple && hipMalloc((void**)&p->work2, P * sizeof(float2)) != hipSuccess))
+        (p->simple && !p->tables_only && hipMalloc((void**)&p->work2, P * sizeof(float2)) != hipSuccess))
         return fail(FDR_ERR_ALLOC, "fdr_plan_create: hipMalloc of the plan workspace failed");
     if (p->fused_norm && hipEventCreateWithFlags(&p->fused_done, hipEventDisableTiming) != hipSuccess)
         return fail(FDR_ERR_HIP, "fdr_plan_create: hipEventCreate failed");
@@ -979,12 +983,14 @@ int fdr_wiener_batch_ptrs_f32(fdr_plan* p, const float* const* imgs_host, float*
 
 int fdr_fft2d_c2c_dev(fdr_plan* p, float* d_data, int inverse, void* stream) {
     if (!p || !d_data) return fail(FDR_ERR_ARG, "fdr_fft2d_c2c_dev: null argument");
+    if (p->tables_only) return fail(FDR_ERR_STATE, "fdr_fft2d_c2c_dev: plan was created with FDR_FLAG_TABLES_ONLY");
     FDR_HIP(hipSetDevice(p->device));
     return dft2d_dev(p, reinterpret_cast<float2*>(d_data), p->work2, inverse != 0, (hipStream_t)stream);
 }
 
 int fdr_fft2d_c2c(fdr_plan* p, float* data_host, int inverse) {
     if (!p || !data_host) return fail(FDR_ERR_ARG, "fdr_fft2d_c2c: null argument");
+    if (p->tables_only) return fail(FDR_ERR_STATE, "fdr_fft2d_c2c: plan was created with FDR_FLAG_TABLES_ONLY");
     FDR_HIP(hipSetDevice(p->device));
     const size_t elems = (size_t)p->M * p->N, bytes = elems * sizeof(float2);
     // p->work is free between operator calls and serves as the staging buffer -- unless the plan keeps only the
@@ -1109,6 +1115,87 @@ int fdr_synth_image_dev(int device, uint64_t seed, uint64_t first_index, size_t 
     if (!d_out && count) return fail(FDR_ERR_ARG, "fdr_synth_image_dev: null output");
     FDR_HIP(hipSetDevice(device));
     FDR_HIP(launch_synth(seed, first_index, count, d_out, (hipStream_t)stream));
+    return FDR_OK;
+}
+
+// ---- slab primitives of the single-image multi-GPU mode (see fdr.h) ----
+int fdr_slab_pad_dev(const float* d_src, int valid_rows, int valid_cols, int src_stride, float* d_dst, int rows, int N, void* stream) {
+    if (!d_dst || rows < 0 || N <= 0 || valid_rows < 0 || valid_cols < 0 || valid_rows > rows || valid_cols > N || (valid_rows && valid_cols && (!d_src || src_stride < valid_cols)))
+        return fail(FDR_ERR_ARG, "fdr_slab_pad_dev: bad argument");
+    if (rows == 0) return FDR_OK;
+    FDR_HIP(launch_pad_real_to_complex(d_src ? d_src : reinterpret_cast<const float*>(d_dst), valid_rows, valid_cols, src_stride > 0 ? src_stride : 1,
+                                       reinterpret_cast<float2*>(d_dst), rows, N, (hipStream_t)stream));
+    return FDR_OK;
+}
+
+int fdr_slab_rows_fft_dev(fdr_plan* p, float* d_complex, int rows, int dim, int inverse, void* stream) {
+    if (!p || !d_complex || rows < 0 || (dim != 0 && dim != 1)) return fail(FDR_ERR_ARG, "fdr_slab_rows_fft_dev: bad argument");
+    if (rows == 0) return FDR_OK;
+    FDR_HIP(hipSetDevice(p->device));
+    const int L = dim == 0 ? p->N : p->M, logl = dim == 0 ? p->logN : p->logM;
+    const float2* twf = dim == 0 ? p->tw_row_f : p->tw_col_f;
+    const float2* twi = dim == 0 ? p->tw_row_i : p->tw_col_i;
+    const float2* naive = dim == 0 ? p->naive_row : p->naive_col;
+    hipStream_t s = (hipStream_t)stream;
+    if (naive) return fail(FDR_ERR_ARG, "fdr_slab_rows_fft_dev: power-of-two dimensions only");
+    float2* d = reinterpret_cast<float2*>(d_complex);
+    if (L >= 8) {
+        RowArgs ra{};
+        ra.src_c = d; ra.dst_c = d; ra.M = rows;
+        // fast mode: the register kernels take the forward table and conjugate it; parity: the table of the direction
+        FDR_HIP(launch_rows(logl, p->mode, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, inverse != 0, ra, p->mode == FDR_MODE_FAST ? twf : (inverse ? twi : twf), s));
+    } else {
+        FDR_HIP(launch_simple_rows(d, rows, L, logl, inverse ? twi : twf, p->mode, s));
+    }
+    return FDR_OK;
+}
+
+int fdr_slab_pack_dev(const void* d_src, int rows, int ld, int parts, const int* counts, int elem_size, void* d_dst, void* stream) {
+    if (!d_src || !d_dst || !counts || rows < 0 || ld <= 0) return fail(FDR_ERR_ARG, "fdr_slab_pack_dev: bad argument");
+    hipError_t e = launch_slab_pack(d_src, rows, ld, parts, counts, elem_size, d_dst, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) return fail(FDR_ERR_ARG, "fdr_slab_pack_dev: 1..16 parts whose counts sum to ld, element size 4 or 8");
+    FDR_HIP(e);
+    return FDR_OK;
+}
+
+int fdr_slab_transpose_dev(const void* d_src, void* d_dst, int rows, int cols, int elem_size, void* stream) {
+    if (!d_src || !d_dst || rows < 0 || cols < 0 || d_src == d_dst) return fail(FDR_ERR_ARG, "fdr_slab_transpose_dev: bad argument");
+    hipError_t e = launch_transpose_any(d_src, d_dst, rows, cols, elem_size, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) return fail(FDR_ERR_ARG, "fdr_slab_transpose_dev: element size 4 or 8");
+    FDR_HIP(e);
+    return FDR_OK;
+}
+
+int fdr_slab_wiener_dev(fdr_plan* p, float* d_g, const float* d_h, size_t count, float K, void* stream) {
+    if (!p || !d_g || !d_h) return fail(FDR_ERR_ARG, "fdr_slab_wiener_dev: null argument");
+    if (count == 0) return FDR_OK;
+    FDR_HIP(hipSetDevice(p->device));
+    // parity: the quotient against H in the reference's operation order; fast: H is turned into W in a scratch-free
+    // second launch first?  No: the slab mode keeps H and uses the parity quotient in both modes (one pointwise pass).
+    FDR_HIP(launch_wiener_pointwise(reinterpret_cast<float2*>(d_g), reinterpret_cast<const float2*>(d_h), count, K, FDR_MODE_PARITY, (hipStream_t)stream));
+    return FDR_OK;
+}
+
+int fdr_slab_real_dev(const float* d_complex, float* d_real, size_t count, void* stream) {
+    if (!d_complex || !d_real) return fail(FDR_ERR_ARG, "fdr_slab_real_dev: null argument");
+    FDR_HIP(launch_real_part(reinterpret_cast<const float2*>(d_complex), d_real, count, (hipStream_t)stream));
+    return FDR_OK;
+}
+
+int fdr_slab_minmax_dev(fdr_plan* p, const float* d_real, int rows, int ld, int mm_rows, int mm_cols, float* d_mm, void* stream) {
+    if (!p || !d_real || !d_mm || rows <= 0 || ld <= 0) return fail(FDR_ERR_ARG, "fdr_slab_minmax_dev: bad argument");
+    FDR_HIP(hipSetDevice(p->device));
+    const long long need = (long long)((ld + 255) / 256) * rows;
+    if (need > p->mm_part_cap) return fail(FDR_ERR_ARG, "fdr_slab_minmax_dev: slab larger than the plan's M x N");
+    int n_part = 0;
+    FDR_HIP(launch_minmax_real(d_real, rows, ld, mm_rows, mm_cols, p->mm_part, &n_part, (hipStream_t)stream));
+    FDR_HIP(launch_reduce_minmax(p->mm_part, n_part, d_mm, (hipStream_t)stream));
+    return FDR_OK;
+}
+
+int fdr_slab_normalize_dev(const float* d_real, int ld, const float* d_mm, float* d_out, int rows, int cols, int out_stride, void* stream) {
+    if (!d_real || !d_mm || !d_out || rows < 0 || cols < 0 || cols > ld || out_stride < cols) return fail(FDR_ERR_ARG, "fdr_slab_normalize_dev: bad argument");
+    FDR_HIP(launch_normalize(d_real, ld, nullptr, 0, d_mm, d_out, rows, cols, out_stride, (hipStream_t)stream));
     return FDR_OK;
 }
 

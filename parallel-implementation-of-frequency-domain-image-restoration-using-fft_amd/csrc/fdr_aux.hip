@@ -448,4 +448,89 @@ hipError_t launch_dft_naive_rows(const float2* src, float2* dst, int rows, int n
     return hipGetLastError();
 }
 
+// ---- building blocks of the single-image multi-GPU mode (slab decomposition; the reference's
+// fft/fft_mpi.cpp:170-307): pack the column blocks of a row slab for the all-to-all, transpose what came back ----
+struct SlabParts { int parts; int counts[16]; int displs[16]; };
+
+// dst = [block 0 | block 1 | ...], block p = src[:, displs[p] : displs[p] + counts[p]] stored row-major (rows x counts[p]);
+// the send buffer of fft/fft_mpi.cpp:118-135 (displs are the prefix sums of counts, so block p starts at rows * displs[p])
+template <class E>
+__global__ void slab_pack_kernel(const E* __restrict__ src, int rows, int ld, SlabParts sp, E* __restrict__ dst) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= ld || r >= rows) return;
+    int p = 0;
+#pragma unroll
+    for (int k = 1; k < 16; ++k)
+        if (k < sp.parts && c >= sp.displs[k]) p = k;
+    dst[(size_t)rows * sp.displs[p] + (size_t)r * sp.counts[p] + (c - sp.displs[p])] = src[(size_t)r * ld + c];
+}
+
+template <class E>
+__global__ void transpose_any_kernel(const E* __restrict__ src, E* __restrict__ dst, int rows, int cols) {
+    __shared__ E tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    int x = blockIdx.x * 32 + tx;
+    for (int j = ty; j < 32; j += 8) {
+        const int y = blockIdx.y * 32 + j;
+        if (x < cols && y < rows) tile[j][tx] = src[(size_t)y * cols + x];
+    }
+    __syncthreads();
+    x = blockIdx.y * 32 + tx;
+    for (int j = ty; j < 32; j += 8) {
+        const int y = blockIdx.x * 32 + j;
+        if (x < rows && y < cols) dst[(size_t)y * rows + x] = tile[tx][j];
+    }
+}
+
+__global__ void real_part_kernel(const float2* __restrict__ src, float* __restrict__ dst, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = src[i].x;
+}
+
+// (min, max) partials of a real rows x ld plane over the counted window [0, mm_rows) x [0, mm_cols)
+__global__ void minmax_real_kernel(const float* __restrict__ src, int rows, int ld, int mm_rows, int mm_cols, float2* __restrict__ part) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    if (x < ld && y < rows && y < mm_rows && x < mm_cols) { mn = mx = src[(size_t)y * ld + x]; }
+    block_minmax_store(mn, mx, part);
+}
+
+hipError_t launch_slab_pack(const void* src, int rows, int ld, int parts, const int* counts, int elem_size, void* dst, hipStream_t s) {
+    if (parts < 1 || parts > 16 || (elem_size != 4 && elem_size != 8)) return hipErrorInvalidValue;
+    SlabParts sp{};
+    sp.parts = parts;
+    int d = 0;
+    for (int k = 0; k < parts; ++k) { sp.counts[k] = counts[k]; sp.displs[k] = d; d += counts[k]; }
+    if (d != ld) return hipErrorInvalidValue;
+    if (rows <= 0 || ld <= 0) return hipSuccess;
+    const dim3 grid((ld + 255) / 256, rows), block(256);
+    if (elem_size == 8) hipLaunchKernelGGL(slab_pack_kernel<float2>, grid, block, 0, s, (const float2*)src, rows, ld, sp, (float2*)dst);
+    else hipLaunchKernelGGL(slab_pack_kernel<float>, grid, block, 0, s, (const float*)src, rows, ld, sp, (float*)dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_transpose_any(const void* src, void* dst, int rows, int cols, int elem_size, hipStream_t s) {
+    if (elem_size != 4 && elem_size != 8) return hipErrorInvalidValue;
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    const dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(256);
+    if (elem_size == 8) hipLaunchKernelGGL(transpose_any_kernel<float2>, grid, block, 0, s, (const float2*)src, (float2*)dst, rows, cols);
+    else hipLaunchKernelGGL(transpose_any_kernel<float>, grid, block, 0, s, (const float*)src, (float*)dst, rows, cols);
+    return hipGetLastError();
+}
+
+hipError_t launch_real_part(const float2* src, float* dst, size_t count, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(real_part_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, src, dst, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_minmax_real(const float* src, int rows, int ld, int mm_rows, int mm_cols, float2* part, int* n_part, hipStream_t s) {
+    const dim3 grid((ld + 255) / 256, rows);
+    *n_part = (int)(grid.x * grid.y);
+    hipLaunchKernelGGL(minmax_real_kernel, grid, dim3(256), 0, s, src, rows, ld, mm_rows, mm_cols, part);
+    return hipGetLastError();
+}
+
 }  // namespace fdr

@@ -128,6 +128,12 @@ int cols_minmax_partials(int logm, int N);
 hipError_t launch_normalize(const float* raw, int N, const float2* mm_part, int n_part, const float* mm, float* out,
                             int rows, int cols, int out_stride, hipStream_t s, const NormBatch* batch = nullptr);
 hipError_t launch_psf_motion(int size, double angle_deg, float* d_out, hipStream_t s);
+// slab mode (single image over several GPUs): column blocks of a row slab packed for the all-to-all, dense transposes
+// of 4- or 8-byte elements, real part, min/max partials of a real plane
+hipError_t launch_slab_pack(const void* src, int rows, int ld, int parts, const int* counts, int elem_size, void* dst, hipStream_t s);
+hipError_t launch_transpose_any(const void* src, void* dst, int rows, int cols, int elem_size, hipStream_t s);
+hipError_t launch_real_part(const float2* src, float* dst, size_t count, hipStream_t s);
+hipError_t launch_minmax_real(const float* src, int rows, int ld, int mm_rows, int mm_cols, float2* part, int* n_part, hipStream_t s);
 
 // colour epilogue of the drivers (fdr_color.hip): planar float BGR in [0,1] -> Lab white balance -> interleaved 8-bit BGR
 struct ColorArgs {

@@ -45,6 +45,26 @@ struct Rows4PackGeom {
     static constexpr int THREADS = T * G;
 };
 
+// Reads every register of a prefetched set through an empty asm: the compiler places the wait for those loads HERE (with
+// the exact vmcnt for this point of the program) and treats them as landed afterwards.  Used at the bottom of the
+// persistent loops, right behind the stores of the group just finished: the prefetch is older than those stores, so the
+// wait is vmcnt(#stores) and the stores keep draining; left to the first use (copies at the loop top, where the state
+// of the first iteration merges in) the compiler emits vmcnt(0..1) and the stores drain before the next transform.
+template <int R, int C>
+__device__ __forceinline__ void landed_f(const float (&d)[R][C]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < C; c += 4) asm volatile("" ::"v"(d[r][c]), "v"(d[r][c + 1]), "v"(d[r][c + 2]), "v"(d[r][c + 3]));
+}
+template <int R, int C>
+__device__ __forceinline__ void landed_f2(const float2 (&d)[R][C]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < C; c += 2) asm volatile("" ::"v"(d[r][c].x), "v"(d[r][c].y), "v"(d[r][c + 1].x), "v"(d[r][c + 1].y));
+}
+
 template <class P>
 __device__ __forceinline__ P pick4(P const (&p)[4], int i) {  // select chain: a dynamic index would send the kernarg array to scratch
     return i == 0 ? p[0] : i == 1 ? p[1] : i == 2 ? p[2] : p[3];
@@ -232,9 +252,10 @@ __global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<
     auto dst_of = [&](int im) -> float2* { return nimg > 1 ? pick4(a.batch.spec, im) : a.dst_c; };
 
     // four image rows of group `g` of image `im`: unconditional loads from clamped coordinates; scale = 0 collapses
-    // every address onto element 0 of the image (no next group)
+    // every address onto element 0 of the image (a prefetch with nothing to fetch: conditional loads would make the
+    // compiler wait for them on the spot)
     float x[4][V];
-    auto request = [&](const float* __restrict__ src, int g, unsigned scale) {
+    auto request = [&](const float* __restrict__ src, int g, unsigned scale) __attribute__((always_inline)) {
         const int r0 = g * 4;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -252,45 +273,36 @@ __global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<
                 }
         }
     };
-    request(src_of(img), grp, 1u);
-
-    while (true) {
-        // pack: z[0] = rows 0 + i 1, z[1] = rows 2 + i 3 (zero padding applied here)
-        float2 z[2][V];
-        {
-            const int r0 = grp * 4;
+    // z[0] = rows 0 + i 1, z[1] = rows 2 + i 3 of group g (zero padding applied here)
+    float2 z[2][V];
+    auto pack = [&](int g) __attribute__((always_inline)) {
+        const int r0 = g * 4;
 #pragma unroll
-            for (int u = 0; u < Core::NU0; ++u)
+        for (int u = 0; u < Core::NU0; ++u)
 #pragma unroll
-                for (int q = 0; q < Core::RHO0; ++q) {
-                    const int s = u * Core::RHO0 + q;
-                    float v0 = x[0][s], v1 = x[1][s], v2 = x[2][s], v3 = x[3][s];
-                    if (!INTERIOR) {
-                        const bool cok = Core::in_index(tid, u, q) < a.src_cols;
-                        v0 = (cok && r0 + 0 < a.src_rows) ? v0 : 0.f;
-                        v1 = (cok && r0 + 1 < a.src_rows) ? v1 : 0.f;
-                        v2 = (cok && r0 + 2 < a.src_rows) ? v2 : 0.f;
-                        v3 = (cok && r0 + 3 < a.src_rows) ? v3 : 0.f;
-                    }
-                    z[0][s] = make_float2(v0, v1);
-                    z[1][s] = make_float2(v2, v3);
+            for (int q = 0; q < Core::RHO0; ++q) {
+                const int s = u * Core::RHO0 + q;
+                float v0 = x[0][s], v1 = x[1][s], v2 = x[2][s], v3 = x[3][s];
+                if (!INTERIOR) {
+                    const bool cok = Core::in_index(tid, u, q) < a.src_cols;
+                    v0 = (cok && r0 + 0 < a.src_rows) ? v0 : 0.f;
+                    v1 = (cok && r0 + 1 < a.src_rows) ? v1 : 0.f;
+                    v2 = (cok && r0 + 2 < a.src_rows) ? v2 : 0.f;
+                    v3 = (cok && r0 + 3 < a.src_rows) ? v3 : 0.f;
                 }
+                z[0][s] = make_float2(v0, v1);
+                z[1][s] = make_float2(v2, v3);
+            }
+    };
+    // transform the packed pair in z, separate the two real rows of each transform and store all four spectra
+    // panel-major: both packed spectra go to LDS in natural order, then a quad of lanes owns one 128-byte line (4 rows x
+    // 4 columns of a panel): lane j of the quad builds row j's four columns (see fft_rows4_fwd_packed_kernel)
+    auto body = [&](int im, int g) __attribute__((always_inline)) {
+        {
+            int tr = tid;  // opaque copy: the exchange addresses are recomputed per group, not carried across the loop
+            asm volatile("" : "+v"(tr));
+            Core::template run<0, false>(z, lds, tw_fwd, bases, tr);
         }
-        // next group of this workgroup
-        const int gn = gi + (int)gridDim.x;
-        const bool more = gn < total;
-        int nimg_i = img, ngrp = grp;
-        if (more) {
-            ngrp += (int)gridDim.x;
-            while (ngrp >= ngroups) { ngrp -= ngroups; ++nimg_i; }
-        }
-        request(src_of(more ? nimg_i : img), more ? ngrp : 0, more ? 1u : 0u);
-
-        Core::template run<0, false>(z, lds, tw_fwd, bases, tid);
-
-        // Separate the two real rows of each packed transform and store all four spectra panel-major: both packed
-        // spectra go to LDS in natural order, then a quad of lanes owns one 128-byte line (4 rows x 4 columns of a
-        // panel): lane j of the quad builds row j's four columns (see fft_rows4_fwd_packed_kernel).
         constexpr int SEQ1 = Core::SLOTS;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -301,40 +313,57 @@ __global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<
                 for (int q = 0; q < Core::RHOL; ++q) buf[Core::out_index(tid, u, q)] = z[b][u * Core::RHOL + q];
         }
         __syncthreads();
-        {
-            float2* __restrict__ dst = dst_of(img);
-            const int r0 = grp * 4;
-            // (opaque copy of the thread index: the LDS and panel addresses below are loop invariant, and hoisted out of
-            // the group loop they would occupy ~25 registers for the whole kernel -- recomputing them costs a few adds)
-            int tq = tid;
-            asm volatile("" : "+v"(tq));
-            const int j = tq & 3;                                            // row inside the 4-row group
-            const float2* buf = lds + ((SEQ1 + (j >> 1)) & 1) * St::BUF;     // packed pair holding row j
-            const bool odd = (j & 1) != 0;                                   // row b of the pair (else row a)
-            constexpr int NIT = (HALF ? L / 8 : L / 4) / (T / 4);            // panels per lane
+        float2* __restrict__ dst = dst_of(im);
+        const int r0 = g * 4;
+        // (opaque copy of the thread index: the LDS and panel addresses below are loop invariant, and hoisted out of
+        // the group loop they would occupy ~25 registers for the whole kernel -- recomputing them costs a few adds)
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const int j = tq & 3;                                            // row inside the 4-row group
+        const float2* buf = lds + ((SEQ1 + (j >> 1)) & 1) * St::BUF;     // packed pair holding row j
+        const bool odd = (j & 1) != 0;                                   // row b of the pair (else row a)
+        constexpr int NIT = (HALF ? L / 8 : L / 4) / (T / 4);            // panels per lane
 #pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const int c = (tq >> 2) + (T / 4) * i;  // panel
-                const int n0 = c * 4;
-                float2 o[4];
+        for (int i = 0; i < NIT; ++i) {
+            const int c = (tq >> 2) + (T / 4) * i;  // panel
+            const int n0 = c * 4;
+            float2 o[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float2 zn = buf[n0 + k];
-                    const float2 zm = buf[(L - n0 - k) & (L - 1)];
-                    o[k] = odd ? make_float2(0.5f * (zn.y + zm.y), 0.5f * (zm.x - zn.x))
-                               : make_float2(0.5f * (zn.x + zm.x), 0.5f * (zn.y - zm.y));
-                }
-                if (HALF && n0 == 0) {  // packed column: (X[0], X[N/2]), both real: Re/Im of Z[0] and Z[N/2]
-                    const float2 z0 = buf[0], zq = buf[L / 2];
-                    o[0] = odd ? make_float2(z0.y, zq.y) : make_float2(z0.x, zq.x);
-                }
-                store4(dst + (size_t)c * a.pstride + (size_t)(r0 + j) * 4, o[0], o[1], o[2], o[3]);
-                asm volatile("" ::: "memory");  // one panel at a time: keeps the LDS reads of later panels from piling up in registers
+            for (int k = 0; k < 4; ++k) {
+                const float2 zn = buf[n0 + k];
+                const float2 zm = buf[(L - n0 - k) & (L - 1)];
+                o[k] = odd ? make_float2(0.5f * (zn.y + zm.y), 0.5f * (zm.x - zn.x))
+                           : make_float2(0.5f * (zn.x + zm.x), 0.5f * (zn.y - zm.y));
             }
+            if (HALF && n0 == 0) {  // packed column: (X[0], X[N/2]), both real: Re/Im of Z[0] and Z[N/2]
+                const float2 z0 = buf[0], zq = buf[L / 2];
+                o[0] = odd ? make_float2(z0.y, zq.y) : make_float2(z0.x, zq.x);
+            }
+            store4(dst + (size_t)c * a.pstride + (size_t)(r0 + j) * 4, o[0], o[1], o[2], o[3]);
         }
+    };
+
+    // Loop shape: the wait for a prefetch sits at the BOTTOM of the loop (pack), behind the stores of the group just
+    // finished.  vmcnt counts loads and stores in issue order and the prefetch is older than those stores, so the wait
+    // there is vmcnt(#stores) and the stores keep draining behind the next transform; with the wait at the loop top the
+    // compiler has to merge it with the first iteration's state (no stores yet) and emits vmcnt(0).
+    request(src_of(img), grp, 1u);
+    landed_f(x);  // (also here: the loop top must see landed values on both of its entries, or it waits again)
+    pack(grp);
+    while (true) {
+        const bool more = gi + (int)gridDim.x < total;
+        int nimg_i = img, ngrp = grp;
+        if (more) {
+            ngrp += (int)gridDim.x;
+            while (ngrp >= ngroups) { ngrp -= ngroups; ++nimg_i; }
+        }
+        request(src_of(nimg_i), more ? ngrp : 0, more ? 1u : 0u);
+        body(img, grp);
         if (!more) break;
+        landed_f(x);      // wait for the prefetch here, behind this group's stores
         __syncthreads();  // the separation's reads are done before the next transform's first exchange writes
-        gi = gn; img = nimg_i; grp = ngrp;
+        pack(ngrp);
+        gi += (int)gridDim.x; img = nimg_i; grp = ngrp;
     }
 }
 
@@ -523,71 +552,96 @@ __global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<
     Core::init_bases(bases, tw_fwd, tid);
 
     float mn = __builtin_inff(), mx = -__builtin_inff();
-    int grp = blockIdx.x;  // (the grid never exceeds the number of groups)
-    float2 y[4][V];
-    rows4_load_raw<LOGL, HALF, Core>(a, grp * 4, tid, y, 1u);
-    while (true) {
-        float2 z[2][V];
-        rows4_pack<LOGL, HALF, Core>(tid, y, z);
-        const int gn = grp + (int)gridDim.x;
-        const bool more = gn < ngroups;
+    float2 y[4][V], z[2][V];
+    auto request = [&](int g, unsigned scale) __attribute__((always_inline)) {
+        int tl = tid;  // opaque copy: the per-lane panel offsets are recomputed per group instead of living in ~16 registers
+        asm volatile("" : "+v"(tl));
+        rows4_load_raw<LOGL, HALF, Core>(a, g * 4, tl, y, scale);
+    };
+    auto body = [&](int g) __attribute__((always_inline)) {
         {
-            int tl = tid;  // opaque copy: the per-lane panel offsets are recomputed per group instead of living in ~16 registers
-            asm volatile("" : "+v"(tl));
-            rows4_load_raw<LOGL, HALF, Core>(a, more ? gn * 4 : 0, tl, y, more ? 1u : 0u);
+            int tr = tid;  // opaque copy: the exchange addresses are recomputed per group, not carried (and spilled) across the loop
+            asm volatile("" : "+v"(tr));
+            Core::template run<0, true>(z, lds, tw_fwd, bases, tr);
         }
-
-        Core::template run<0, true>(z, lds, tw_fwd, bases, tid);
-
-        {
-            const int r0 = grp * 4;
-            int tq = tid;  // opaque copy: keeps the store addresses from being hoisted out of the group loop
-            asm volatile("" : "+v"(tq));
-            float* o0 = a.dst_real + (size_t)r0 * L + tq;
-            float* o1 = o0 + L;
-            float* o2 = o1 + L;
-            float* o3 = o2 + L;
+        const int r0 = g * 4;
+        int tq = tid;  // opaque copy: keeps the store addresses from being hoisted out of the group loop
+        asm volatile("" : "+v"(tq));
+        float* o0 = a.dst_real + (size_t)r0 * L + tq;
+        float* o1 = o0 + L;
+        float* o2 = o1 + L;
+        float* o3 = o2 + L;
+#pragma unroll
+        for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+            for (int q = 0; q < Core::RHOL; ++q) {
+                const int s = u * Core::RHOL + q;
+                const int c = u * T + (q << Core::LOGOUT);
+                o0[c] = z[0][s].x; o1[c] = z[0][s].y; o2[c] = z[1][s].x; o3[c] = z[1][s].y;
+            }
+        if (r0 + 3 < a.mm_rows && a.mm_cols >= L) {  // whole group counted (always, with FDR_NORM_PADDED)
+#pragma unroll
+            for (int s = 0; s < V; ++s) {
+                mn = fminf(fminf(mn, z[0][s].x), fminf(z[0][s].y, fminf(z[1][s].x, z[1][s].y)));
+                mx = fmaxf(fmaxf(mx, z[0][s].x), fmaxf(z[0][s].y, fmaxf(z[1][s].x, z[1][s].y)));
+            }
+        } else {
 #pragma unroll
             for (int u = 0; u < Core::NUL; ++u)
 #pragma unroll
                 for (int q = 0; q < Core::RHOL; ++q) {
                     const int s = u * Core::RHOL + q;
-                    const int c = u * T + (q << Core::LOGOUT);
-                    o0[c] = z[0][s].x; o1[c] = z[0][s].y; o2[c] = z[1][s].x; o3[c] = z[1][s].y;
+                    const int n = Core::out_index(tq, u, q);
+                    const float r[4] = {z[0][s].x, z[0][s].y, z[1][s].x, z[1][s].y};
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (r0 + b < a.mm_rows && n < a.mm_cols) {
+                            mn = fminf(mn, r[b]);
+                            mx = fmaxf(mx, r[b]);
+                        }
                 }
-            if (r0 + 3 < a.mm_rows && a.mm_cols >= L) {  // whole group counted (always, with FDR_NORM_PADDED)
-#pragma unroll
-                for (int s = 0; s < V; ++s) {
-                    mn = fminf(fminf(mn, z[0][s].x), fminf(z[0][s].y, fminf(z[1][s].x, z[1][s].y)));
-                    mx = fmaxf(fmaxf(mx, z[0][s].x), fmaxf(z[0][s].y, fmaxf(z[1][s].x, z[1][s].y)));
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < Core::NUL; ++u)
-#pragma unroll
-                    for (int q = 0; q < Core::RHOL; ++q) {
-                        const int s = u * Core::RHOL + q;
-                        const int n = Core::out_index(tq, u, q);
-                        const float r[4] = {z[0][s].x, z[0][s].y, z[1][s].x, z[1][s].y};
-#pragma unroll
-                        for (int b = 0; b < 4; ++b)
-                            if (r0 + b < a.mm_rows && n < a.mm_cols) {
-                                mn = fminf(mn, r[b]);
-                                mx = fmaxf(mx, r[b]);
-                            }
-                    }
-            }
         }
+    };
+    // loop shape as in fft_rows4_fwd_pers_kernel: the prefetch is waited for at the bottom (pack), behind the stores
+    int grp = blockIdx.x;  // (the grid never exceeds the number of groups)
+    request(grp, 1u);
+    landed_f2(y);
+    rows4_pack<LOGL, HALF, Core>(tid, y, z);
+    while (true) {
+        const int gn = grp + (int)gridDim.x;
+        const bool more = gn < ngroups;
+        if constexpr (LOGV == 3) {
+            // 128-register budget: the three hoisted twiddle bases do not survive the loop in registers; fetched again
+            // here (L1 hits), BEFORE the prefetch is issued -- a reload behind it (a spill slot is vector memory too)
+            // could only be waited for together with the whole prefetch
+            int tb = tid;
+            asm volatile("" : "+v"(tb));
+            Core::init_bases(bases, tw_fwd, tb);
+        }
+        request(more ? gn : 0, more ? 1u : 0u);
+        body(grp);
         if (!more) break;
+        landed_f2(y);     // wait for the prefetch here, behind this group's stores
+        __syncthreads();  // keeps the two transforms' LDS traffic apart
+        rows4_pack<LOGL, HALF, Core>(tid, y, z);
         grp = gn;
-        // (no barrier needed here: the last exchange of the transform ended with every thread's reads, and the next
-        // transform's first exchange writes the OTHER buffer when the slot count per run is odd -- it is not in
-        // general, so keep the two runs apart)
-        __syncthreads();
     }
     block_minmax_store(mn, mx, a.mm_part, (int)blockIdx.x);
 }
 
+// persistent pass C' is used when a workgroup gets more than one group (else there is nothing to overlap); always for
+// 8192-point rows (see launch_rows4_t)
+template <int LOGL>
+static int rows4_inv_pers_grid(int M, int num_cu, int nimg);
+template <int LOGL>
+static bool rows4_inv_use_pers(int M, int num_cu, int nimg) {
+    if constexpr (LOGL >= 11) {
+        if ((M & 3) != 0) return false;
+        return LOGL >= 13 || rows4_inv_pers_grid<LOGL>(M, num_cu, nimg) < (M + 3) / 4;
+    } else {
+        return false;
+    }
+}
 // persistent pass C': workgroups per image (the number of min/max partials the pass writes for one image)
 template <int LOGL>
 static int rows4_inv_pers_grid(int M, int num_cu, int nimg) {
@@ -855,11 +909,14 @@ static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const f
     const dim3 grid((groups + Geo::G - 1) / Geo::G, nimg), block(Geo::THREADS);
     if (in == ROW_IN_REAL && out == ROW_OUT_COMPLEX) {
         if constexpr (LOGL >= 11 && FDR_ROWS_PERSISTENT) {
-            if ((a.M & 3) == 0 && a.src_rows > 0 && a.src_cols > 0) {  // persistent, prefetching form
-                constexpr int LOGV = LOGL >= 13 ? 4 : (LOGL == 12 ? FDR_ROWS12_LOGV : 3);
-                using PG = RowsPersGeom<LOGL, LOGV>;
-                const int total = groups * nimg;
-                int g = (a.num_cu > 0 ? a.num_cu : 256) * PG::WG_PER_CU;
+            constexpr int LOGV = LOGL >= 13 ? 4 : (LOGL == 12 ? FDR_ROWS12_LOGV : 3);
+            using PG = RowsPersGeom<LOGL, LOGV>;
+            const int total = groups * nimg;
+            int g = (a.num_cu > 0 ? a.num_cu : 256) * PG::WG_PER_CU;
+            // persistent, prefetching form -- when a workgroup gets more than one group (else there is nothing to overlap
+            // and the one-group-per-workgroup kernel has less to do); always for 8192-point rows, which the 8-value
+            // kernel can only run as 1024-thread workgroups
+            if ((a.M & 3) == 0 && a.src_rows > 0 && a.src_cols > 0 && (total > g || LOGL >= 13)) {
                 if (g > total) g = total;
                 const bool interior = a.src_rows >= a.M && a.src_cols >= (1 << LOGL);
                 const dim3 pgrid(g), pblock(PG::THREADS);
@@ -877,9 +934,9 @@ static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const f
         else hipLaunchKernelGGL((fft_rows4_fwd_packed_kernel<LOGL, false>), grid, block, 0, s, a, tw);
     } else if (in == ROW_IN_COMPLEX && out == ROW_OUT_REAL_MINMAX) {
         if constexpr (LOGL >= 11 && FDR_ROWS_PERSISTENT) {
-            if ((a.M & 3) == 0) {
-                constexpr int LOGV = LOGL >= 13 ? 4 : (LOGL == 12 ? FDR_ROWS12_LOGV : 3);
-                using PG = RowsPersGeom<LOGL, LOGV>;
+            constexpr int LOGV = LOGL >= 13 ? 4 : (LOGL == 12 ? FDR_ROWS12_LOGV : 3);
+            using PG = RowsPersGeom<LOGL, LOGV>;
+            if (rows4_inv_use_pers<LOGL>(a.M, a.num_cu, nimg)) {
                 const dim3 pgrid(rows4_inv_pers_grid<LOGL>(a.M, a.num_cu, nimg), nimg), pblock(PG::THREADS);
                 if (a.half) hipLaunchKernelGGL((fft_rows4_inv_pers_kernel<LOGL, LOGV, true>), pgrid, pblock, 0, s, a, tw, groups);
                 else hipLaunchKernelGGL((fft_rows4_inv_pers_kernel<LOGL, LOGV, false>), pgrid, pblock, 0, s, a, tw, groups);
@@ -897,7 +954,7 @@ static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const f
 template <int LOGL>
 static int rows4_partials_t(int M, int num_cu, int nimg) {
     if constexpr (LOGL >= 11 && FDR_ROWS_PERSISTENT) {
-        if ((M & 3) == 0) return rows4_inv_pers_grid<LOGL>(M, num_cu, nimg);
+        if (rows4_inv_use_pers<LOGL>(M, num_cu, nimg)) return rows4_inv_pers_grid<LOGL>(M, num_cu, nimg);
     }
     return ((M + 3) / 4 + Rows4PackGeom<LOGL>::G - 1) / Rows4PackGeom<LOGL>::G;
 }

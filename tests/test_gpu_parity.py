@@ -686,3 +686,22 @@ def test_constant_image_normalises_to_zero(fdr, oracle):
         got = fdr.wienerDeblur_myfft(img, psf, 0.01, mode=mode)
         _assert_same(got, oracle.serial_channel(img, psf, 0.01), "constant image")
         assert np.all(got == 0.0)
+
+
+@pytest.mark.parametrize("rows,cols,world,extra", [(1024, 2048, 2, []), (782, 1920, 2, []), (100, 200, 3, ["--cropped"]), (64, 64, 1, [])])
+def test_single_image_slab_mode_equals_single_gpu(rows, cols, world, extra):
+    """SURVEY 8f-3 / fft/fft_mpi.cpp:170-307: ONE image as row slabs over `world` ranks, the 2-D transform as local row
+    passes + all-to-all transposes (..._amd/slab.py over the fdr_slab_* kernels).  Rehearsal on one GPU (every rank on
+    cuda:0, backend gloo, exchanges staged through the host); the gathered picture must equal the single-GPU parity-mode
+    result bit for bit (and therefore the oracle).  Unmeasured on multi-GPU hardware."""
+    import json, subprocess, sys
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    port = 29700 + (_os.getpid() + rows) % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), _os.path.join(root, "tests", "_slab_worker.py"), str(rows), str(cols), "50" if min(rows, cols) >= 64 and rows > 100 else "15",
+           "--one-device", "--backend", "gloo"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["world"] == world and r["shape"] == [rows, cols] and sum(r["slab_rows"]) == rows
+    assert r["mismatch_vs_single_gpu"] == 0 and r["mismatch_vs_oracle"] == 0, r

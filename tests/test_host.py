@@ -90,3 +90,18 @@ def test_two_rank_gloo():
     r = json.loads(line)
     assert r["world"] == 2 and r["images"] == 11 and r["index_sum"] == sum(range(11))
     assert r["elapsed"] >= 3 * 0.004  # MAX over ranks: the slower rank (2 * 2 ms per step) bounds it
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gloo_alltoall_transpose_logic():
+    """The exchange of the single-image multi-GPU mode (..._amd/slab.py: calculate_distribution + all_to_all_single with
+    the block sizes of fft/fft_mpi.cpp:118-147) on CPU tensors under gloo, world_size 2 and 3: blocks packed and
+    transposed with numpy here (the device kernels that do it in the product are covered by the GPU tests)."""
+    for world in (2, 3):
+        port = 29900 + (os.getpid() % 90) + world
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "tests", "_a2a_worker.py"), "10", "7"]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=170, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert r["world"] == world and r["ok"] is True, r
