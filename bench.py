@@ -149,11 +149,13 @@ def main():
     spectrum = "half" if (args.mode == "fast" and not (flags & fdr.FLAG_FULL_SPECTRUM) and S >= 32) else "full"
     plan = fdr.Plan(S, S, mode, device=local_rank, flags=flags)
     stream = torch.cuda.current_stream().cuda_stream
-    # measured best: 4096^2 and up 3 streams x 1 image per launch; small images 2 streams x 4 images per launch
+    # measured best (tools/microbench/passbench, profiles/README.md): every pass runs 10-17 % faster per image when a
+    # launch covers more than one image (launch gaps and the ramp-up / drain of a grid amortise), so images go in
+    # groups: up to 2048^2 2 streams x 4 images per launch, 4096^2 2 x 2, 8192^2 3 x 2 (streams x group <= 8 workspaces)
     if args.streams <= 0:
-        args.streams = 2 if (S <= 2048 and args.mode == "fast") else 3
+        args.streams = (2 if S <= 4096 else 3) if args.mode == "fast" else 3
     if args.group <= 0:
-        args.group = max(1, min(4, 8 // args.streams)) if S <= 2048 else 1
+        args.group = 4 if S <= 2048 else 2
     plan.set_batching(args.streams, args.group if args.mode == "fast" else 1)
     plan.set_psf_motion(50, 30.0, 0.01, stream=stream)  # PSF generated, padded and transformed on the device
     imgs = torch.empty((max(B, 1), S, S), dtype=torch.float32, device=dev)

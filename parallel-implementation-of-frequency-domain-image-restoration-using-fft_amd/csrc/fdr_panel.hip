@@ -215,7 +215,16 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
 //             256-register budget (the 8-value form needs 1024 threads at 128 registers and cannot hold a prefetch)
 // ---------------------------------------------------------------------------------------------
 #ifndef FDR_ROWS12_LOGV
-#define FDR_ROWS12_LOGV 3  // values per thread (log2) of the persistent row passes for rows of 2048 / 4096 points
+#define FDR_ROWS12_LOGV 3  // values per thread (log2) of the persistent row passes for rows of 4096 points (A/B builds)
+#endif
+// Shortest rows (log2) that take the persistent form.  Measured on MI355X (passbench, 24 x 4096^2 / 6 x 8192^2 / 32 x
+// 2048^2, us per image, one-group-per-workgroup kernel vs persistent):  8192: A 144.6 -> 121.7, C' 155.2 -> 143.1;
+// 4096: A 34.7 -> 36.2, C' 31.2 -> 34.1;  2048 (4 images per launch): A 8.1 -> 9.0, C' 6.9 -> 8.3.  With the transform
+// compiled out the 4096^2 row passes take 28.5 / 23.8 us: only 6-7 us of transform are exposed there, less than the
+// persistent form's own cost (dummy prefetch, barrier, fewer independent workgroups), so it is used for 8192-point rows
+// only, where the alternative is a 1024-thread workgroup alone on its CU.
+#ifndef FDR_ROWS_PERS_MIN_LOG
+#define FDR_ROWS_PERS_MIN_LOG 13
 #endif
 template <int LOGL, int LOGV>
 struct RowsPersGeom {
@@ -908,7 +917,7 @@ static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const f
     const int nimg = a.batch.nimg > 1 ? a.batch.nimg : 1;
     const dim3 grid((groups + Geo::G - 1) / Geo::G, nimg), block(Geo::THREADS);
     if (in == ROW_IN_REAL && out == ROW_OUT_COMPLEX) {
-        if constexpr (LOGL >= 11 && FDR_ROWS_PERSISTENT) {
+        if constexpr (LOGL >= FDR_ROWS_PERS_MIN_LOG && FDR_ROWS_PERSISTENT) {
             constexpr int LOGV = LOGL >= 13 ? 4 : (LOGL == 12 ? FDR_ROWS12_LOGV : 3);
             using PG = RowsPersGeom<LOGL, LOGV>;
             const int total = groups * nimg;
@@ -933,7 +942,7 @@ static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const f
         if (a.half) hipLaunchKernelGGL((fft_rows4_fwd_packed_kernel<LOGL, true>), grid, block, 0, s, a, tw);
         else hipLaunchKernelGGL((fft_rows4_fwd_packed_kernel<LOGL, false>), grid, block, 0, s, a, tw);
     } else if (in == ROW_IN_COMPLEX && out == ROW_OUT_REAL_MINMAX) {
-        if constexpr (LOGL >= 11 && FDR_ROWS_PERSISTENT) {
+        if constexpr (LOGL >= FDR_ROWS_PERS_MIN_LOG && FDR_ROWS_PERSISTENT) {
             constexpr int LOGV = LOGL >= 13 ? 4 : (LOGL == 12 ? FDR_ROWS12_LOGV : 3);
             using PG = RowsPersGeom<LOGL, LOGV>;
             if (rows4_inv_use_pers<LOGL>(a.M, a.num_cu, nimg)) {
@@ -953,7 +962,7 @@ static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const f
 
 template <int LOGL>
 static int rows4_partials_t(int M, int num_cu, int nimg) {
-    if constexpr (LOGL >= 11 && FDR_ROWS_PERSISTENT) {
+    if constexpr (LOGL >= FDR_ROWS_PERS_MIN_LOG && FDR_ROWS_PERSISTENT) {
         if (rows4_inv_use_pers<LOGL>(M, num_cu, nimg)) return rows4_inv_pers_grid<LOGL>(M, num_cu, nimg);
     }
     return ((M + 3) / 4 + Rows4PackGeom<LOGL>::G - 1) / Rows4PackGeom<LOGL>::G;
