@@ -403,37 +403,51 @@ __device__ __forceinline__ void rows4_load_raw(const RowArgs& a, int rr, int tid
         static_assert(Core::RHO0 >= 2 && Core::LOGR0 >= 2, "n = t + q Q with Q a multiple of 4");
         const unsigned ps = (unsigned)a.pstride * scale;  // scale = 0: every address collapses onto rows 0..3 of panel 0 (a prefetch with nothing to fetch)
         rr = (int)((unsigned)rr * scale);
+        constexpr unsigned PMID = (unsigned)(L / 8);  // panel of column L/2 (one past the stored panels)
+        unsigned off_d[Core::NU0], off_m[Core::NU0];
 #pragma unroll
         for (int u = 0; u < Core::NU0; ++u) {
             const unsigned t = (unsigned)(tid + u * Core::T);        // n = t + q Q,  Q = 2^LOGR0 (a multiple of 4)
             const unsigned ta = t >> 2, tb = t & 3u;
             // direct half: stored column t + qQ -> panel qQ/4 + ta, column tb
-            const unsigned off_d = ta * ps + tb * scale + (unsigned)rr * 4u;
-            // mirrored half: stored column (RHO0 - q) Q - t -> panel (RHO0-q)Q/4 - ta - (tb != 0), column (4 - tb) & 3;
-            // relative to q = RHO0/2 (panel L/8): the lane part is folded into an offset from panel (L/8 - T NU0/4 ... ) >= 0
-            constexpr unsigned PMID = (unsigned)(L / 8);              // panel of column L/2 (one past the stored panels)
+            off_d[u] = ta * ps + tb * scale + (unsigned)rr * 4u;
+            // mirrored half: stored column (RHO0 - q) Q - t -> panel (RHO0-q)Q/4 - ta - (tb != 0), column (4 - tb) & 3,
+            // relative to q = RHO0/2 (panel L/8)
             const unsigned pm = PMID - ta - (tb != 0u ? 1u : 0u);     // panel of the mirrored column at q = RHO0/2
-            const unsigned off_m = pm * ps + ((4u - tb) & 3u) * scale + (unsigned)rr * 4u;
-            // n = L/2 (lane t = 0 of the q = RHO0/2 slot): the Nyquist value rides in column 0 of panel 0
-            const unsigned off_n = (u == 0 && t == 0u) ? (unsigned)rr * 4u : off_m;
-#pragma unroll
-            for (int q = 0; q < Core::RHO0; ++q) {
-                const int s = u * Core::RHO0 + q;
+            off_m[u] = pm * ps + ((4u - tb) & 3u) * scale + (unsigned)rr * 4u;
+        }
+        auto load_slot = [&](int u, int q) __attribute__((always_inline)) {
+            const int s = u * Core::RHO0 + q;
 #ifdef FDR_DEBUG_SKIP_MEM  // timing-only builds
-                y[0][s] = y[1][s] = y[2][s] = y[3][s] = make_float2((float)(off_d + q), (float)(off_m + off_n));
+            y[0][s] = y[1][s] = y[2][s] = y[3][s] = make_float2((float)(off_d[u] + q), (float)(off_m[u]));
 #else
-                const float2* p;
-                if (q < Core::RHO0 / 2) {
-                    p = a.src_c + (size_t)((q << Core::LOGR0) >> 2) * ps + off_d;
-                } else if (q == Core::RHO0 / 2) {
-                    p = a.src_c + off_n;
-                } else {  // (RHO0 - q) Q = L/2 - (q - RHO0/2) Q: uniform step back from the q = RHO0/2 panel
-                    p = a.src_c - (size_t)(((q - Core::RHO0 / 2) << Core::LOGR0) >> 2) * ps + off_m;
-                }
-                y[0][s] = p[0]; y[1][s] = p[4]; y[2][s] = p[8]; y[3][s] = p[12];
+            const float2* p;
+            if (q < Core::RHO0 / 2) {
+                p = a.src_c + (size_t)((q << Core::LOGR0) >> 2) * ps + off_d[u];
+            } else if (q == Core::RHO0 / 2) {
+                // n = L/2 (lane t = 0 of the u = 0 slot): the Nyquist value rides in column 0 of panel 0
+                const unsigned off_n = (u == 0 && tid == 0) ? (unsigned)rr * 4u : off_m[u];
+                p = a.src_c + off_n;
+            } else {  // (RHO0 - q) Q = L/2 - (q - RHO0/2) Q: uniform step back from the q = RHO0/2 panel
+                p = a.src_c - (size_t)(((q - Core::RHO0 / 2) << Core::LOGR0) >> 2) * ps + off_m[u];
+            }
+            y[0][s] = p[0]; y[1][s] = p[4]; y[2][s] = p[8]; y[3][s] = p[12];
+#endif
+        };
+        // Issue order: every stored line is read twice by the workgroup, once for a direct slot and once for the mirrored
+        // slot that covers the same block of panels -- direct (u, q) and mirrored (NU0-1-u, RHO0-1-q).  Requested back to
+        // back the second touch finds the line in (or on its way into) L1 / L2; in slot order the two are half a tile of
+        // loads apart and the second one goes out to the fabric again (measured at 8192^2: 372 MB read for 268 MB stored).
+#pragma unroll
+        for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+            for (int q = 0; q < Core::RHO0 / 2; ++q) {
+                load_slot(u, q);
+                load_slot(Core::NU0 - 1 - u, Core::RHO0 - 1 - q);
+#ifndef FDR_DEBUG_SKIP_MEM
+                asm volatile("" ::: "memory");
 #endif
             }
-        }
     }
 }
 template <int LOGL, bool HALF, class Core>
@@ -461,9 +475,84 @@ __device__ __forceinline__ void rows4_pack(int tid, const float2 (&y)[4][Core::V
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same rebuild WITHOUT the second touch of memory (half-spectrum plans, rows of 32 points and more).  The packed
+// input of the inverse transform is Z[n] = Y_a[n] + i Y_b[n]; for the upper half, Z[N-n] = conj(Y_a[n]) + i conj(Y_b[n])
+// -- a function of the SAME two stored values.  So a thread loads only its direct slots (stored columns n < N/2: half
+// the gathers of rows4_load_raw, every stored line requested once), forms Z[n] for itself and Z[N-n] for whichever
+// thread owns index N-n, and hands the latter over through LDS in natural order (the exchange buffers are idle at that
+// point): 4 V / 8 writes + reads per thread and two barriers, against V/2 x 4 eight-byte gathers that went out to the
+// fabric a second time (fabric reads of pass C' measured at 1.10x / 1.45x the stored bytes at 4096^2 / 8192^2).
+//   y[row][j], j = u (RHO0/2) + q : stored column in_index(tid, u, q), q < RHO0/2
+// ---------------------------------------------------------------------------------------------
+template <int LOGL, class Core>
+__device__ __forceinline__ void rows4_load_direct(const RowArgs& a, int rr, int tid, float2 (&y)[4][Core::V / 2], unsigned scale = 1u) {
+    static_assert(Core::RHO0 >= 2 && Core::LOGR0 >= 2, "n = t + q Q with Q a multiple of 4");
+    constexpr int HQ = Core::RHO0 / 2;
+    const unsigned ps = (unsigned)a.pstride * scale;  // scale = 0: every address collapses onto rows 0..3 of panel 0
+    rr = (int)((unsigned)rr * scale);
+#pragma unroll
+    for (int u = 0; u < Core::NU0; ++u) {
+        const unsigned t = (unsigned)(tid + u * Core::T);  // stored column t + q Q -> panel q Q / 4 + t / 4, column t & 3
+        const unsigned off_d = (t >> 2) * ps + (t & 3u) * scale + (unsigned)rr * 4u;
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) {
+            const int j = u * HQ + q;
+#ifdef FDR_DEBUG_SKIP_MEM  // timing-only builds
+            y[0][j] = y[1][j] = y[2][j] = y[3][j] = make_float2((float)(off_d + q), 1.0f);
+#else
+            const float2* p = a.src_c + (size_t)((q << Core::LOGR0) >> 2) * ps + off_d;
+            y[0][j] = p[0]; y[1][j] = p[4]; y[2][j] = p[8]; y[3][j] = p[12];
+#endif
+        }
+    }
+}
+// z[0] = Y_a + i Y_b of rows 0, 1, z[1] of rows 2, 3; grp_lds: the thread group's two exchange buffers.  Barriers inside
+// (every thread of the workgroup must come here); returns with both buffers free again.
+template <int LOGL, class Core>
+__device__ __forceinline__ void rows4_pack_mirror(int tid, const float2 (&y)[4][Core::V / 2], float2 (&z)[2][Core::V], float2* grp_lds) {
+    using St = typename Core::St;
+    constexpr int L = St::L, HQ = Core::RHO0 / 2;
+    float2* m0 = grp_lds;
+    float2* m1 = grp_lds + St::BUF;
+#pragma unroll
+    for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) {
+            const int j = u * HQ + q, s = u * Core::RHO0 + q;
+            const int n = Core::in_index(tid, u, q);
+            const float2 y0 = y[0][j], y1 = y[1][j], y2 = y[2][j], y3 = y[3][j];
+            z[0][s] = make_float2(y0.x - y1.y, y0.y + y1.x);  // Y_a + i Y_b
+            z[1][s] = make_float2(y2.x - y3.y, y2.y + y3.x);
+            // conj(Y_a) + i conj(Y_b) belongs to index N - n (n = 0 has no mirror: it is the packed DC / Nyquist column)
+            const int k = (L - n) & (L - 1);
+            if (!(u == 0 && q == 0) || tid != 0) {
+                m0[k] = make_float2(y0.x + y1.y, y1.x - y0.y);
+                m1[k] = make_float2(y2.x + y3.y, y3.x - y2.y);
+            }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+        for (int q = HQ; q < Core::RHO0; ++q) {
+            const int s = u * Core::RHO0 + q;
+            const int k = Core::in_index(tid, u, q);
+            z[0][s] = m0[k];
+            z[1][s] = m1[k];
+        }
+    if (tid == 0) {  // n = 0 (DC) and n = L/2 (Nyquist): real values packed as (DC, Nyquist) in stored column 0
+        constexpr int SN = HQ;  // slot of n = L/2 (u = 0, q = RHO0/2); its LDS cell was never written
+        z[0][0] = make_float2(y[0][0].x, y[1][0].x);
+        z[1][0] = make_float2(y[2][0].x, y[3][0].x);
+        z[0][SN] = make_float2(y[0][0].y, y[1][0].y);
+        z[1][SN] = make_float2(y[2][0].y, y[3][0].y);
+    }
+    __syncthreads();  // the transform's first exchange may overwrite either buffer
+}
+
 // HALF: the row spectra hold columns 0 .. N/2-1 only, column 0 packed as Y[m,0] + i Y[m,N/2] (see the forward
-// kernel); the upper half is rebuilt on load as the conjugate of the mirrored column (every stored line is
-// touched twice by the same workgroup, the second time from L1/L2).
+// kernel); the upper half is rebuilt as the conjugate of the mirrored column (rows4_pack_mirror).
 template <int LOGL, bool HALF>
 __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_packed_kernel(const RowArgs a0,
                                                                                           const float2* __restrict__ tw_fwd) {
@@ -488,7 +577,11 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_pa
     Core::init_bases(bases, tw_fwd, tid);
 
     float2 z[2][8];
-    {
+    if constexpr (HALF && LOGL >= 5) {  // direct half from memory, mirrored half through LDS
+        float2 y[4][4];
+        rows4_load_direct<LOGL, Core>(a, rr, tid, y);
+        rows4_pack_mirror<LOGL, Core>(tid, y, z, lds + g * 2 * St::BUF);
+    } else {
         float2 y[4][8];
         rows4_load_raw<LOGL, HALF, Core>(a, rr, tid, y);
         rows4_pack<LOGL, HALF, Core>(tid, y, z);
@@ -561,11 +654,17 @@ __global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<
     Core::init_bases(bases, tw_fwd, tid);
 
     float mn = __builtin_inff(), mx = -__builtin_inff();
-    float2 y[4][V], z[2][V];
+    constexpr bool MIRROR = HALF;  // direct half from memory, mirrored half through LDS (rows4_pack_mirror)
+    float2 y[4][MIRROR ? V / 2 : V], z[2][V];
     auto request = [&](int g, unsigned scale) __attribute__((always_inline)) {
         int tl = tid;  // opaque copy: the per-lane panel offsets are recomputed per group instead of living in ~16 registers
         asm volatile("" : "+v"(tl));
-        rows4_load_raw<LOGL, HALF, Core>(a, g * 4, tl, y, scale);
+        if constexpr (MIRROR) rows4_load_direct<LOGL, Core>(a, g * 4, tl, y, scale);
+        else rows4_load_raw<LOGL, HALF, Core>(a, g * 4, tl, y, scale);
+    };
+    auto pack = [&]() __attribute__((always_inline)) {
+        if constexpr (MIRROR) rows4_pack_mirror<LOGL, Core>(tid, y, z, lds);
+        else rows4_pack<LOGL, HALF, Core>(tid, y, z);
     };
     auto body = [&](int g) __attribute__((always_inline)) {
         {
@@ -615,7 +714,7 @@ __global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<
     int grp = blockIdx.x;  // (the grid never exceeds the number of groups)
     request(grp, 1u);
     landed_f2(y);
-    rows4_pack<LOGL, HALF, Core>(tid, y, z);
+    pack();
     while (true) {
         const int gn = grp + (int)gridDim.x;
         const bool more = gn < ngroups;
@@ -632,7 +731,7 @@ __global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<
         if (!more) break;
         landed_f2(y);     // wait for the prefetch here, behind this group's stores
         __syncthreads();  // keeps the two transforms' LDS traffic apart
-        rows4_pack<LOGL, HALF, Core>(tid, y, z);
+        pack();
         grp = gn;
     }
     block_minmax_store(mn, mx, a.mm_part, (int)blockIdx.x);
@@ -1244,6 +1343,11 @@ __device__ __forceinline__ void tile_load(const float2* __restrict__ ubase, unsi
 #else
             const gchar* ub = uniform_gptr(ubase + uoff);
             FDR_GLOAD32(ub, lo, d[0][s], d[1][s], d[2][s], d[3][s]);
+            // keep the two 16-byte halves of a row together in the instruction stream: left alone the scheduler issues the
+            // 16 first halves of a tile, then the 16 second halves, and with every wave of an XCD doing the same (8 MB of
+            // lines requested before the first second half) part of the lines has left the 4 MiB L2 again by then
+            // (measured: +9 % fabric reads in the 4096-point column pass)
+            asm volatile("" ::: "memory");
 #endif
         }
 }
