@@ -364,13 +364,28 @@ __device__ __forceinline__ void radix16_fast(float2 (&v)[B][V], float2 base) {
 // lds: this group's NBUF * Steps::BUF float2 region.  SEQ0: how many exchange slots were already
 // consumed on this region (keeps the double-buffer parity hazard-free across chained calls).
 // ---------------------------------------------------------------------------------------------
-template <int LOGL, int B, int NBUF, class Pol, int LOGV = 3>
+// SWAP0: the exchange behind a radix-2 FIRST step (LOGL mod LOGV = 1, e.g. 8192 = 2 x 16 x 16 x 16) without LDS.  After
+// that step thread t holds Y[t + T u][k], u < V/2, k < 2, and the next step wants Y[r0 + (T/2) q][k'], q < V, with
+// r0 = t mod T/2 and k' = t div T/2: all sources of a thread are the thread itself and its partner t +- T/2.  With the
+// logical thread index laid out so that the partners are lanes l and l + 32 of ONE wave (thread_index below), the
+// exchange is `v_permlane32_swap_b32` on the register pair (Y[..][0], Y[..][1]) of every u: V/2 x 2 swaps per transform
+// instead of a full LDS round trip with two barriers (the LDS store path, ~85 B/clk per CU, is what bounds the
+// 8192-point passes: 7 round trips per column pair of transforms before, 4 now together with permute_out_to_in).
+// Kernels that instantiate a SWAP0 core must take their thread index from thread_index(threadIdx.x).
+template <int LOGL, int B, int NBUF, class Pol, int LOGV = 3, bool SWAP0 = false>
 struct FftCore {
     using St = Steps<LOGL, LOGV>;
     static constexpr int V = St::V;
     static constexpr int S = St::S;
     static constexpr int T = St::T;
     static constexpr int SLOTS = (S - 1) * B;  // exchange slots one run() consumes
+    static_assert(!SWAP0 || (St::lr(0) == 1 && S >= 2 && T >= 64), "SWAP0: radix-2 first step, at least one wave per transform");
+
+    // logical thread index of physical thread p of a T-thread group (identity unless SWAP0)
+    static __device__ __forceinline__ int thread_index(int p) {
+        if constexpr (SWAP0) return (((p >> 6) << 5) | (p & 31)) + (T / 2) * ((p >> 5) & 1);
+        else return p;
+    }
 
     // index helpers for the first-step loads and last-step stores
     static constexpr int NU0 = St::nu(0), RHO0 = 1 << St::lr(0), LOGR0 = St::logR(0);
@@ -467,13 +482,57 @@ struct FftCore {
         }
     }
 
+    // exchange 0 of a SWAP0 core: lanes l < 32 keep k = 0 and collect the partner's k = 0 values, lanes l >= 32 keep k = 1;
+    // v_permlane32_swap_b32 vdst, src swaps vdst's lanes 32..63 with src's lanes 0..31, so with vdst = Y[..][0] and
+    // src = Y[..][1] both registers end up holding this lane's own k: vdst the even q (= 2u), src the odd q (= 2u + 1)
+    static __device__ __forceinline__ void exchange_swap(float2 (&v)[B][V]) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+        (void)v;  // host pass of the translation unit: device code only
+#elif __has_builtin(__builtin_amdgcn_permlane32_swap)
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+            for (int u = 0; u < V / 2; ++u) {
+                const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[b][2 * u].x), __float_as_uint(v[b][2 * u + 1].x), false, false);
+                const auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[b][2 * u].y), __float_as_uint(v[b][2 * u + 1].y), false, false);
+                v[b][2 * u] = make_float2(__uint_as_float(rx[0]), __uint_as_float(ry[0]));
+                v[b][2 * u + 1] = make_float2(__uint_as_float(rx[1]), __uint_as_float(ry[1]));
+            }
+#else
+        static_assert(!SWAP0, "v_permlane32_swap_b32 (gfx950) is not available to this compiler");
+#endif
+    }
+
     template <int J, int SEQ0, bool INV>
     static __device__ __forceinline__ void steps_from(float2 (&v)[B][V], float2* lds, const float2* __restrict__ tw,
                                                       const Bases& bs, int tid) {
         butterflies<J, INV>(v, tw, bs, tid);
         if constexpr (J + 1 < S) {
-            exchange<J, SEQ0>(v, lds, tid);
+            if constexpr (SWAP0 && J == 0) exchange_swap(v);
+            else exchange<J, SEQ0>(v, lds, tid);
             steps_from<J + 1, SEQ0, INV>(v, lds, tw, bs, tid);
+        }
+    }
+
+    // Last-step result order -> first-step operand order, for chaining a second transform (forward . filter . inverse).
+    // Both are the SAME thread's values: element indices are tid + T j, j < V, with j = u + (q << (LOGV - lr)) in either
+    // order, so the change of order is a renaming of registers -- no exchange.
+    static __device__ __forceinline__ void permute_out_to_in(float2 (&v)[B][V]) {
+        constexpr int SH_OUT = LOGV - St::lr(S - 1), SH_IN = LOGV - St::lr(0);
+        if constexpr (LOGL >= LOGV && SH_OUT != SH_IN) {
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                float2 t[V];
+#pragma unroll
+                for (int s = 0; s < V; ++s) t[s] = v[b][s];
+#pragma unroll
+                for (int u = 0; u < NU0; ++u)
+#pragma unroll
+                    for (int q = 0; q < RHO0; ++q) {
+                        const int j = u + (q << SH_IN);                                   // element tid + T j
+                        v[b][u * RHO0 + q] = t[(j & (NUL - 1)) * RHOL + (j >> SH_OUT)];   // out slot (u', q') with u' + (q' << SH_OUT) = j
+                    }
+            }
         }
     }
 

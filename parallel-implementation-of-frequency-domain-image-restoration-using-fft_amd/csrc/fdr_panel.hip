@@ -214,6 +214,9 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
 //   LOGV = 4: 16 values per thread, T = L/16 threads: 8192-point rows as ONE 512-thread workgroup per CU with a
 //             256-register budget (the 8-value form needs 1024 threads at 128 registers and cannot hold a prefetch)
 // ---------------------------------------------------------------------------------------------
+#ifndef FDR_SWAP0
+#define FDR_SWAP0 1  // v_permlane32_swap exchange behind a radix-2 first step (8192-point transforms on the 16-value core)
+#endif
 #ifndef FDR_ROWS12_LOGV
 #define FDR_ROWS12_LOGV 3  // values per thread (log2) of the persistent row passes for rows of 4096 points (A/B builds)
 #endif
@@ -244,9 +247,9 @@ __global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<
     const RowArgs a, const float2* __restrict__ tw_fwd, const int ngroups, const int total) {
     using St = Steps<LOGL, LOGV>;
     constexpr int T = St::T, L = St::L, V = St::V;
-    using Core = FftCore<LOGL, 2, 2, PolicyFast, LOGV>;
+    using Core = FftCore<LOGL, 2, 2, PolicyFast, LOGV, (St::lr(0) == 1 && FDR_SWAP0)>;  // 8192 points: wave-local first exchange
     __shared__ float2 lds[2 * St::BUF];
-    const int tid = threadIdx.x;
+    const int tid = Core::thread_index(threadIdx.x);
     const int nimg = a.batch.nimg > 1 ? a.batch.nimg : 1;
 
     typename Core::Bases bases;
@@ -646,9 +649,9 @@ __global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<
     }
     using St = Steps<LOGL, LOGV>;
     constexpr int T = St::T, L = St::L, V = St::V;
-    using Core = FftCore<LOGL, 2, 2, PolicyFast, LOGV>;
+    using Core = FftCore<LOGL, 2, 2, PolicyFast, LOGV, (St::lr(0) == 1 && FDR_SWAP0)>;  // 8192 points: wave-local first exchange
     __shared__ float2 lds[2 * St::BUF];
-    const int tid = threadIdx.x;
+    const int tid = Core::thread_index(threadIdx.x);
 
     typename Core::Bases bases;
     Core::init_bases(bases, tw_fwd, tid);
@@ -1201,25 +1204,6 @@ __device__ __forceinline__ void panel_store_out(float2* __restrict__ pbase, int 
     }
 }
 
-// last-step result order -> first-step operand order through LDS when the two radices differ
-template <int LOGM, class Core, int SEQ>
-__device__ __forceinline__ void redistribute(float2 (&cur)[4][Core::V], float2* grp_lds, int tid) {
-    using St = typename Core::St;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        float2* buf = grp_lds + ((SEQ + b) & 1) * St::BUF;
-#pragma unroll
-        for (int u = 0; u < Core::NUL; ++u)
-#pragma unroll
-            for (int q = 0; q < Core::RHOL; ++q) buf[Core::out_index(tid, u, q)] = cur[b][u * Core::RHOL + q];
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < Core::NU0; ++u)
-#pragma unroll
-            for (int q = 0; q < Core::RHO0; ++q) cur[b][u * Core::RHO0 + q] = buf[Core::in_index(tid, u, q)];
-    }
-}
-
 // forward column FFT of every panel, in place (PSF spectrum)
 template <int LOGM>
 __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PER_SIMD) void fft_cols_panel_fwd_kernel(
@@ -1409,12 +1393,8 @@ __device__ __forceinline__ void panel_tile(float2 (&cur)[4][8], float2 (&flt)[4]
     }
     tile_load<Core, false>(n.data, n.loff, nscale, flt);  // next spectrum streams in behind the inverse transform
     constexpr int SEQ1 = Core::SLOTS;
-    if constexpr (Core::RHOL != Core::RHO0) {
-        redistribute<LOGM, Core, SEQ1>(cur, grp_lds, tid);
-        Core::template run<SEQ1 + 4, true>(cur, grp_lds, tw_fwd, bases, tid);
-    } else {
-        Core::template run<SEQ1, true>(cur, grp_lds, tw_fwd, bases, tid);
-    }
+    Core::permute_out_to_in(cur);  // (a renaming of registers when the first and the last radix differ)
+    Core::template run<SEQ1, true>(cur, grp_lds, tw_fwd, bases, tid);
     landed(flt);
     if (c.ok) tile_store<Core>(c.data, c.loff, cur);
     tile_load<Core, true>(n.filt, n.loff, nscale, cur);   // next filter streams in behind the next forward transform
@@ -1501,6 +1481,7 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::PIPE_WAV
 #ifndef FDR_COLS12_PACKED
 #define FDR_COLS12_PACKED 1
 #endif
+
 template <int LOGM>
 struct Panel16Geom {
     static constexpr int T = Steps<LOGM, 4>::T;
@@ -1516,10 +1497,11 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
     const int npanels, const int ntiles, const int packed0) {
     using St = Steps<LOGM, 4>;
     constexpr int G = Panel16Geom<LOGM>::G, T = St::T, M = St::L, V = 16;
-    using Core = FftCore<LOGM, 4, 2, typename std::conditional<(LOGM == 12 && !FDR_COLS12_PACKED), PolicyFastScalar, PolicyFast>::type, 4>;  // see PolicyFastScalar
+    using Core = FftCore<LOGM, 4, 2, typename std::conditional<(LOGM == 12 && !FDR_COLS12_PACKED), PolicyFastScalar, PolicyFast>::type, 4,
+                         (St::lr(0) == 1 && T >= 64 && FDR_SWAP0)>;  // see PolicyFastScalar; 8192 points: wave-local first exchange
     __shared__ float2 lds[G * 2 * St::BUF];
     const int g = G == 1 ? 0 : (int)(threadIdx.x >> St::LOGT);
-    const int tid = threadIdx.x & (T - 1);
+    const int tid = Core::thread_index(threadIdx.x & (T - 1));
     float2* grp_lds = lds + g * 2 * St::BUF;
     // grid (ntiles, images): an integer division here would run on the VALU and drag every tile address into VGPRs
     const int img = blockIdx.y, tl = blockIdx.x;
@@ -1632,12 +1614,8 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
         // common subexpressions they would stay alive across the filter phase, where register pressure peaks
         int ti = tid;
         asm volatile("" : "+v"(ti));
-        if constexpr (Core::RHOL != Core::RHO0) {
-            redistribute<LOGM, Core, SEQ>(v, grp_lds, ti);
-            Core::template run<SEQ + 4, true>(v, grp_lds, tw_fwd, bases, ti);
-        } else {
-            Core::template run<SEQ, true>(v, grp_lds, tw_fwd, bases, ti);
-        }
+        Core::permute_out_to_in(v);  // (a renaming of registers when the first and the last radix differ)
+        Core::template run<SEQ, true>(v, grp_lds, tw_fwd, bases, ti);
     }
     FDR_STAMP(pb, wgid, 5);
     if (active) tile_store<Core>(data, loff, v);
