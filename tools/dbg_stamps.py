@@ -1,4 +1,4 @@
-"""Timeline of the fused C'+E kernel from a -DFDR_DEBUG_STAMPS build (tools/bench_dbg.sh builds):
+"""Timeline of the fused C'+E kernel from a -DFDR_DEBUG_STAMPS build (make -C <package> OBJDIR=build_dbg/stamps LIB=build_dbg/libfdr_stamps.so EXTRA=-DFDR_DEBUG_STAMPS; plan flag FDR_FLAG_FUSED_NORM):
    FDR_LIB_PATH=.../build_dbg/libfdr_stamps.so python tools/dbg_stamps.py [size]"""
 import ctypes, importlib, sys, os
 import numpy as np
@@ -7,7 +7,7 @@ import torch
 fdr = importlib.import_module("parallel-implementation-of-frequency-domain-image-restoration-using-fft_amd")
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 nwg = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-with fdr.Plan(S, S, fdr.MODE_FAST) as p:
+with fdr.Plan(S, S, fdr.MODE_FAST, flags=fdr.FLAG_FUSED_NORM) as p:
     p.set_psf_motion(50, 30.0, 0.01)
     img = torch.rand((S, S), device="cuda")
     out = torch.empty_like(img)
