@@ -45,6 +45,36 @@ def test_argument_validation_precedes_any_device_work(fdr):
     assert fdr.lib.fdr_psf_motion(0, 30.0, None) == -1
 
 
+def test_new_entry_points_validate_arguments_before_device_work(fdr):
+    """fdr_batch_run / fdr_slab_* / options / phase times: null and out-of-range arguments are rejected before any HIP
+    call (so this runs without a GPU); fdr_optimal_dft_size is pure host arithmetic (cv::getOptimalDFTSize)."""
+    L = fdr.lib
+    assert [fdr.getOptimalDFTSize(n) for n in (1, 2, 7, 11, 17, 782, 1920, 4097)] == [1, 2, 8, 12, 18, 800, 1920, 4320]
+    assert L.fdr_batch_run(None, None) == -1
+    d = fdr.BatchDesc()
+    assert L.fdr_batch_run(ctypes.byref(d), None) == -1 and b"device entries" in L.fdr_last_error()
+    devs = (ctypes.c_int * 1)(0)
+    d.n_devices, d.devices, d.M, d.N, d.rows, d.cols, d.count = 1, devs, 64, 64, 65, 64, 1
+    assert L.fdr_batch_run(ctypes.byref(d), None) == -1 and b"batch shape" in L.fdr_last_error()
+    d.rows, d.steps = 64, 0
+    assert L.fdr_batch_run(ctypes.byref(d), None) == -1 and b"steps" in L.fdr_last_error()
+    d.steps, d.psf_size = 1, 0
+    assert L.fdr_batch_run(ctypes.byref(d), None) == -1 and b"PSF" in L.fdr_last_error()
+    assert L.fdr_plan_set_option(None, 1, 5) == -1
+    assert L.fdr_plan_phase_times(None, None, 0) == -1
+    assert L.fdr_slab_rows_fft_dev(None, None, 1, 0, 0, None) == -1
+    assert L.fdr_slab_pack_dev(None, 1, 4, 1, None, 8, None, None) == -1
+    assert L.fdr_slab_transpose_dev(None, None, 1, 1, 8, None) == -1
+    assert L.fdr_slab_pad_dev(None, 0, 0, 0, None, 1, 8, None) == -1
+    assert L.fdr_slab_wiener_dev(None, None, None, 0, ctypes.c_float(0.01), None) == -1
+    assert L.fdr_slab_minmax_dev(None, None, 1, 1, 1, 1, None, None) == -1
+    assert L.fdr_slab_normalize_dev(None, 1, None, None, 1, 1, 1, None) == -1
+    assert L.fdr_slab_real_dev(None, None, 0, None) == -1
+    h = ctypes.c_void_p()
+    assert L.fdr_plan_create(0, 100, 64, 0, 0, ctypes.byref(h)) == -2                       # not a power of two ...
+    assert L.fdr_plan_create(0, 5000, 64, 0, fdr.FLAG_ANY_SIZE, ctypes.byref(h)) == -1     # ... and too long for the naive-DFT table
+
+
 def test_no_cpu_fallback_in_product_package():
     """The product path must not reach into oracle/ (or any numpy FFT) -- checked textually."""
     pkg_dir = os.path.join(ROOT, PKG)
