@@ -27,5 +27,9 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -o cal -- ./too
 # N > 1 path of bench.py on the one GPU: two ranks, gloo, both on cuda:0 (torchrun is started before anything touches the GPU)
 python3 bench.py --gpus 2 --backend gloo --one-device --size 2048 --batch 32 --steps 5 --warmup 2 --repeats 3 --no-psf-recompute > $OUT/two_rank_weak.log 2>&1; echo "two_rank_weak rc=$?" >> $OUT/status.txt
 python3 bench.py --gpus 2 --backend gloo --one-device --size 2048 --total-batch 63 --steps 5 --warmup 2 --repeats 3 --no-psf-recompute > $OUT/two_rank_strong.log 2>&1; echo "two_rank_strong rc=$?" >> $OUT/status.txt
+# BASELINE config 5 on the one GPU (512 x 2048^2, device resident) and config 2's size (1024^2)
+python3 bench.py --size 2048 --total-batch 512 --steps 10 --warmup 2 --repeats 3 > $OUT/config5_one_gpu.log 2>&1; echo "config5_one_gpu rc=$?" >> $OUT/status.txt
+python3 bench.py --size 1024 --batch 256 --steps 10 --warmup 2 --repeats 3 > $OUT/config2_size.log 2>&1; echo "config2_size rc=$?" >> $OUT/status.txt
+python3 bench.py --size 8192 --batch 24 --steps 6 --warmup 2 --repeats 3 --cpu-size 8192 > $OUT/config4_size.log 2>&1; echo "config4_size rc=$?" >> $OUT/status.txt
 cat $OUT/status.txt
 cut -c1-400 $OUT/bench_line.json
