@@ -195,7 +195,7 @@ def main():
     # ---- second figure: the PSF spectrum rebuilt for every image, as the reference's loop does per channel
     #      (fft/fft_gpu.cu:329-343,356): PSF generation + pad + 2-D FFT + filter inside the step, one stream ----
     psf_elapsed = None
-    if not args.no_psf_recompute and B > 0:
+    if not args.no_psf_recompute:  # (every rank takes part in the barriers, also one whose shard is empty)
         nb = min(B, 16)
 
         def step_psf():
@@ -263,7 +263,7 @@ def main():
                   "parallelism": "images sharded over %d rank(s), no data-path collective" % world,
                   "normalize_area": "padded (serial semantics)",
                   "repeats": len(reps), "value_min": round(vals[0], 1), "value_max": round(vals[-1], 1),
-                  "value_with_psf_recompute": round(psf_images * P / 1e6 / psf_elapsed, 1) if psf_elapsed else None}
+                  "value_with_psf_recompute": round(psf_images * P / 1e6 / psf_elapsed, 1) if (psf_elapsed and psf_images) else None}
         line = {
             "metric": "Mpixels/sec restored (FFT+Wiener+IFFT) at %dx%d fp32" % (S, S),
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
