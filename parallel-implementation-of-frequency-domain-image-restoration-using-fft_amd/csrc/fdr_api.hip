@@ -1253,10 +1253,10 @@ int batch_worker_run(const fdr_batch_desc* d, BatchWorker* w, std::chrono::stead
             return FDR_OK;
         }
         // synthetic, device resident
-        // defaults as bench.py's (measured): up to 2048^2 2 streams x 4 images per launch, 4096^2 2 x 2, larger 3 x 2
+        // defaults as bench.py's (measured): up to 4096^2 2 streams x 4 images per launch, larger 3 x 2
         const size_t px = (size_t)d->M * (size_t)d->N;
         const int ns = d->nstreams > 0 ? d->nstreams : (px <= (size_t)4096 * 4096 ? 2 : 3);
-        const int gr = d->group > 0 ? d->group : (px <= (size_t)2048 * 2048 ? 4 : 2);
+        const int gr = d->group > 0 ? d->group : (px <= (size_t)4096 * 4096 ? 4 : 2);
         r = fdr_plan_set_batching(plan, ns, d->mode == FDR_MODE_FAST ? gr : 1);
         if (r != FDR_OK) return r;
         const size_t P = (size_t)d->rows * d->cols, total = P * (size_t)w->count;

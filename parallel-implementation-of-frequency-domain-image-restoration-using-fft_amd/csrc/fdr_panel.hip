@@ -1478,6 +1478,9 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::PIPE_WAV
 #ifndef FDR_WPIECE
 #define FDR_WPIECE 4
 #endif
+#ifndef FDR_SHARE_W
+#define FDR_SHARE_W 1
+#endif
 #ifndef FDR_COLS12_PACKED
 #define FDR_COLS12_PACKED 1
 #endif
@@ -1494,7 +1497,7 @@ struct Panel16Geom {
 template <int LOGM>
 __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_fused16_kernel(
     const PanelBatch pb, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const unsigned pstride,
-    const int npanels, const int ntiles, const int packed0) {
+    const int npanels, const int ntiles, const int packed0, const int img_shift) {
     using St = Steps<LOGM, 4>;
     constexpr int G = Panel16Geom<LOGM>::G, T = St::T, M = St::L, V = 16;
     using Core = FftCore<LOGM, 4, 2, typename std::conditional<(LOGM == 12 && !FDR_COLS12_PACKED), PolicyFastScalar, PolicyFast>::type, 4,
@@ -1503,8 +1506,17 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
     const int g = G == 1 ? 0 : (int)(threadIdx.x >> St::LOGT);
     const int tid = Core::thread_index(threadIdx.x & (T - 1));
     float2* grp_lds = lds + g * 2 * St::BUF;
-    // grid (ntiles, images): an integer division here would run on the VALU and drag every tile address into VGPRs
-    const int img = blockIdx.y, tl = blockIdx.x;
+    // Two mappings of workgroups to (tile, image), both free of integer divisions (which would run on the VALU and drag
+    // every tile address into VGPRs).  img_shift < 0: grid (ntiles, images).  Otherwise (2 or 4 images, tiles a multiple
+    // of 8): a flat grid in which the workgroups that share a tile -- and so its slice of the filter W -- are neighbours
+    // on the SAME XCD (workgroup b lands on XCD b % 8), so W crosses the fabric once per tile, not once per image.
+    int img, tl;
+    if (img_shift < 0) { img = blockIdx.y; tl = blockIdx.x; }
+    else {
+        const int b = blockIdx.x, j = b >> 3;
+        img = j & ((1 << img_shift) - 1);
+        tl = ((j >> img_shift) << 3) | (b & 7);
+    }
     const bool active = tl * G + g < npanels;
     const size_t tbase = (size_t)(tl * G) * pstride;
     float2* __restrict__ data = (img == 0 ? pb.data[0] : img == 1 ? pb.data[1] : img == 2 ? pb.data[2] : pb.data[3]) + tbase;
@@ -1516,7 +1528,7 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
 
     // (Delaying the workgroup that landed in the odd wave slots by half a load phase, so that the two workgroups of
     // a CU alternate between memory and LDS phases, was measured: no gain up to 5 us of delay, slower beyond.)
-    const int wgid = blockIdx.y * gridDim.x + blockIdx.x; (void)wgid;
+    const int wgid = img * ntiles + tl; (void)wgid;
     FDR_STAMP(pb, wgid, 0);
     float2 v[4][V];
     tile_load<Core, false>(data, loff, 1u, v);
@@ -1642,8 +1654,10 @@ static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const floa
         if constexpr (LOGM >= 10) {  // 16 values per thread: one workgroup per tile, grid (tiles, images)
             using G16 = Panel16Geom<LOGM>;
             const int nt16 = (npanels + G16::G - 1) / G16::G;
-            hipLaunchKernelGGL((fft_cols_panel_fused16_kernel<LOGM>), dim3(nt16, pb.nimg), dim3(G16::THREADS), 0, s, pb, a.filt, tw,
-                               (unsigned)ps, npanels, nt16, a.packed0);
+            const int ishift = FDR_SHARE_W && (nt16 % 8 == 0) ? (pb.nimg == 2 ? 1 : pb.nimg == 4 ? 2 : -1) : -1;
+            const dim3 grid16 = ishift < 0 ? dim3(nt16, pb.nimg) : dim3(nt16 * pb.nimg);
+            hipLaunchKernelGGL((fft_cols_panel_fused16_kernel<LOGM>), grid16, dim3(G16::THREADS), 0, s, pb, a.filt, tw,
+                               (unsigned)ps, npanels, nt16, a.packed0, ishift);
         } else {                     // short columns: persistent radix-8 kernel, register double-buffered
             const int total = ntiles * pb.nimg;
             int grid = (a.num_cu > 0 ? a.num_cu : 256) * Geo::PIPE_WG_PER_CU;
