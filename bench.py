@@ -152,9 +152,9 @@ def main():
     # measured best (tools/microbench/passbench, profiles/README.md): every pass runs 10-17 % faster per image when a
     # launch covers more than one image (launch gaps and the ramp-up / drain of a grid amortise; in pass B' the
     # workgroups of one tile share its slice of the filter W in their XCD's L2), so images go in groups: up to 4096^2
-    # 2 streams x 4 images per launch, 8192^2 3 x 2 (streams x group <= 8 workspaces)
+    # 2 streams x 4 images per launch, 8192^2 2 x 2 (24 x 8192^2: 3 x 2 145 k, 2 x 4 142 k, 2 x 2 150 k Mpixels/s)
     if args.streams <= 0:
-        args.streams = (2 if S <= 4096 else 3) if args.mode == "fast" else 3
+        args.streams = 2 if args.mode == "fast" else 3
     if args.group <= 0:
         args.group = 4 if S <= 4096 else 2
     plan.set_batching(args.streams, args.group if args.mode == "fast" else 1)

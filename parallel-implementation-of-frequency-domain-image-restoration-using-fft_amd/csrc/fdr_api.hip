@@ -1253,9 +1253,9 @@ int batch_worker_run(const fdr_batch_desc* d, BatchWorker* w, std::chrono::stead
             return FDR_OK;
         }
         // synthetic, device resident
-        // defaults as bench.py's (measured): up to 4096^2 2 streams x 4 images per launch, larger 3 x 2
+        // defaults as bench.py's (measured): 2 streams; up to 4096^2 4 images per launch, larger 2
         const size_t px = (size_t)d->M * (size_t)d->N;
-        const int ns = d->nstreams > 0 ? d->nstreams : (px <= (size_t)4096 * 4096 ? 2 : 3);
+        const int ns = d->nstreams > 0 ? d->nstreams : (d->mode == FDR_MODE_FAST ? 2 : 3);
         const int gr = d->group > 0 ? d->group : (px <= (size_t)4096 * 4096 ? 4 : 2);
         r = fdr_plan_set_batching(plan, ns, d->mode == FDR_MODE_FAST ? gr : 1);
         if (r != FDR_OK) return r;

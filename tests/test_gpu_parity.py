@@ -356,6 +356,32 @@ def test_batched_multistream_equals_one_by_one(fdr, oracle, mode_name):
         _assert_same(one[2], oracle.serial_channel(host[2], psf, 0.01), "batched vs oracle")
 
 
+@pytest.mark.parametrize("shape", [(1000, 40), (1024, 20), (2000, 100)])
+def test_grouped_long_column_launches_equal_one_by_one(fdr, oracle, shape):
+    """Pass B' on columns of 1024 points and more puts the images of one launch on neighbouring workgroups of one XCD
+    (they share the tile's slice of W) when the launch has 2 or 4 images and the tile count is a multiple of 8, and
+    falls back to a (tiles, images) grid otherwise: every grouping must give the bits of the one-by-one path."""
+    import torch
+    rows, cols = shape
+    B = 7
+    M, N = 1 << (rows - 1).bit_length(), 1 << (cols - 1).bit_length()
+    psf = oracle.motion_blur_kernel(15, 30.0)
+    host = np.stack([_image(oracle, rows, cols, 300 + i) for i in range(B)])
+    d_in = torch.from_numpy(host).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    with fdr.Plan(M, N, fdr.MODE_FAST) as p:
+        p.set_psf(psf, 0.01)
+        one = np.stack([p.wiener(host[i]) for i in range(B)])
+        for nstreams, group in ((1, 2), (2, 2), (1, 3), (1, 4), (2, 4)):  # 7 = 2+2+2+1 = 3+3+1 = 4+3
+            d_g = torch.zeros_like(d_in)
+            p.set_batching(nstreams, group)
+            p.wiener_batch_dev(d_in.data_ptr(), rows * cols, B, rows, cols, cols, d_g.data_ptr(), rows * cols, cols, stream=s)
+            torch.cuda.synchronize()
+            assert np.count_nonzero(~(d_g.cpu().numpy() == one)) == 0, (nstreams, group)
+    ref = oracle.serial_channel(host[5], psf, 0.01)
+    assert float(np.max(np.abs(one[5] - ref))) <= 1e-4
+
+
 @pytest.mark.parametrize("pinned", [False, True])
 @pytest.mark.parametrize("mode_name", ["MODE_PARITY", "MODE_FAST"])
 def test_host_batch_pipeline_equals_one_by_one(fdr, oracle, mode_name, pinned):
