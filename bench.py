@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--size", type=int, default=4096, help="synthetic image edge (power of two)")
     ap.add_argument("--batch", type=int, default=96, help="images per GPU per step")
     ap.add_argument("--mode", choices=["fast", "parity"], default="fast")
-    ap.add_argument("--streams", type=int, default=0, help="internal streams / workspaces the batch alternates over (0 = 3, or 2 up to 2048^2)")
+    ap.add_argument("--streams", type=int, default=0, help="internal streams / workspaces the batch alternates over (0 = 2 in fast mode, 3 in parity mode)")
     ap.add_argument("--group", type=int, default=0, help="images per pass-B' launch (fast mode; 1..4, streams*group <= 8; 0 = 4 up to 4096^2, else 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals on a one-GPU box)")
