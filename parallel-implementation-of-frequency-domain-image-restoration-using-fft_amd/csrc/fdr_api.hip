@@ -166,6 +166,7 @@ struct fdr_plan {
     // fused pass C'+E (fast panel path, half spectrum, images of at most 4 row groups per CU)
     bool fused_norm = false; int fused_R = 0, fused_nwg = 0;
     unsigned spin_limit = 20000;     // sweeps (~0.5 us each) before a waiting workgroup falls back
+    bool two_sweep = false;          // FDR_OPT_TWO_SWEEP_NORM: passes C1 + C2 instead of C' + E (fast half-spectrum path)
     hipEvent_t fused_done = nullptr; // fused launches of one plan never overlap: each holds every CU while it waits
     bool fused_recorded = false;
 };
@@ -225,6 +226,11 @@ const char* const kPassRowsInvRealN[5] = {nullptr, nullptr, "C' rows: IFFT+real+
                                          "C' rows: IFFT+real+minmax [4 images]"};
 const char* const kPassNormalizeN[5] = {nullptr, nullptr, "E normalize+crop [2 images]", "E normalize+crop [3 images]", "E normalize+crop [4 images]"};
 const char* const kPassNormalize = "E normalize+crop";
+const char* const kPassRowsMinmax = "C1 rows: IFFT+minmax";
+const char* const kPassRowsMinmaxN[5] = {nullptr, nullptr, "C1 rows: IFFT+minmax [2 images]", "C1 rows: IFFT+minmax [3 images]", "C1 rows: IFFT+minmax [4 images]"};
+const char* const kPassRowsNorm = "C2 rows: IFFT+normalize+crop";
+const char* const kPassRowsNormN[5] = {nullptr, nullptr, "C2 rows: IFFT+normalize+crop [2 images]", "C2 rows: IFFT+normalize+crop [3 images]",
+                                       "C2 rows: IFFT+normalize+crop [4 images]"};
 const char* const kPassRowsInvNorm = "C'E rows: IFFT+minmax+normalize+crop (fused)";
 const char* const kPassFixup = "E' fixup (no-op unless a wait timed out)";
 const char* const kPassSimple = "simple path (reference-shaped)";
@@ -386,6 +392,25 @@ int panel_stage_CE(fdr_plan* p, fdr_plan::Slot& w, int rows, int cols, float* d_
         }
         return FDR_OK;
     }
+    if (p->two_sweep && p->half) {
+        // C1 + C2: the inverse row transform runs twice -- once for the min/max alone, once more with the normalisation
+        // applied on store -- so the raw real plane never exists: 4 + 8 bytes per pixel instead of 8 + 8
+        RowArgs a{};
+        a.src_c = w.work; a.mm_part = w.mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
+        a.pstride = p->pstride; a.half = 1; a.num_cu = p->num_cu;
+        a.out = d_out; a.out_rows = rows; a.out_cols = cols; a.out_stride = out_stride;
+        a.n_part = rows4_minmax_partials(p->logN, p->M, p->num_cu, 1);
+        if (a.n_part <= 0 || a.n_part > p->mm_part_cap) return fail(FDR_ERR_STATE, "fdr_wiener: min/max partial count out of range");
+        {
+            ScopedPass t(p, s, kPassRowsMinmax);
+            FDR_HIP(launch_rows4(p->logN, ROW_IN_COMPLEX, ROW_OUT_MINMAX_ONLY, a, p->tw_row_f, s));
+        }
+        {
+            ScopedPass t(p, s, kPassRowsNorm);
+            FDR_HIP(launch_rows4(p->logN, ROW_IN_COMPLEX, ROW_OUT_NORMALIZED, a, p->tw_row_f, s));
+        }
+        return FDR_OK;
+    }
     {   // C': 4 rows rebuilt from the panels, inverse, real plane, min/max partials
         ScopedPass t(p, s, kPassRowsInvReal);
         RowArgs a{};
@@ -417,6 +442,28 @@ int panel_stage_A_batch(fdr_plan* p, fdr_plan::Slot* const* ws, int n, const flo
 }
 int panel_stage_CE_batch(fdr_plan* p, fdr_plan::Slot* const* ws, int n, int rows, int cols, float* const* d_outs, int out_stride,
                          int mm_rows, int mm_cols, hipStream_t s) {
+    if (p->two_sweep) {  // C1 + C2 (see panel_stage_CE)
+        RowArgs a{};
+        a.src_c = ws[0]->work; a.mm_part = ws[0]->mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
+        a.pstride = p->pstride; a.half = 1; a.num_cu = p->num_cu;
+        a.out = d_outs[0]; a.out_rows = rows; a.out_cols = cols; a.out_stride = out_stride;
+        a.n_part = rows4_minmax_partials(p->logN, p->M, p->num_cu, n);
+        if (a.n_part <= 0 || a.n_part > p->mm_part_cap) return fail(FDR_ERR_STATE, "fdr_wiener: min/max partial count out of range");
+        a.batch.nimg = n;
+        for (int k = 0; k < 4; ++k) {
+            const fdr_plan::Slot* w = ws[k < n ? k : 0];
+            a.batch.spec[k] = w->work; a.batch.mm_part[k] = w->mm_part; a.batch.out[k] = d_outs[k < n ? k : 0];
+        }
+        {
+            ScopedPass t(p, s, kPassRowsMinmaxN[n]);
+            FDR_HIP(launch_rows4(p->logN, ROW_IN_COMPLEX, ROW_OUT_MINMAX_ONLY, a, p->tw_row_f, s));
+        }
+        {
+            ScopedPass t(p, s, kPassRowsNormN[n]);
+            FDR_HIP(launch_rows4(p->logN, ROW_IN_COMPLEX, ROW_OUT_NORMALIZED, a, p->tw_row_f, s));
+        }
+        return FDR_OK;
+    }
     {
         ScopedPass t(p, s, kPassRowsInvRealN[n]);
         RowArgs a{};
@@ -674,6 +721,10 @@ int fdr_plan_dims(const fdr_plan* p, int* M, int* N, int* mode) {
 int fdr_plan_set_option(fdr_plan* p, int option, long long value) {
     if (!p) return fail(FDR_ERR_ARG, "fdr_plan_set_option: null plan");
     switch (option) {
+        case FDR_OPT_TWO_SWEEP_NORM:
+            if (value != 0 && value != 1) return fail(FDR_ERR_ARG, "fdr_plan_set_option: FDR_OPT_TWO_SWEEP_NORM takes 0 or 1");
+            p->two_sweep = value != 0;
+            return FDR_OK;
         case FDR_OPT_FUSED_SPIN_LIMIT:
             if (value < 0 || value > 0xffffffffLL) return fail(FDR_ERR_ARG, "fdr_plan_set_option: spin limit out of range");
             p->spin_limit = (unsigned)value;
@@ -1399,3 +1450,11 @@ int fdr_plan_pass_times(fdr_plan* p, int* n_passes, float* mean_ms, const char**
 }
 
 }  // extern "C"
+
+#ifdef FDR_DIAG  // diagnostic builds only (tools/diag): the addresses of a slot's intermediates
+extern "C" int fdr_debug_slot_ptrs(fdr_plan* p, int slot, void** work, void** raw, void** mm_part, size_t* ws_elems) {
+    if (!p || slot < 0 || slot >= fdr_plan::kMaxSlots) return FDR_ERR_ARG;
+    *work = p->slots[slot].work; *raw = p->slots[slot].raw; *mm_part = p->slots[slot].mm_part; *ws_elems = p->ws_elems;
+    return FDR_OK;
+}
+#endif

@@ -583,4 +583,43 @@ __device__ __forceinline__ void minmax_to_scale_shift(float mn, float mx, float&
     fshift = 0.0f - (float)(smin * scale);
 }
 
+// every workgroup folds the n_part per-workgroup (min, max) partials of an image itself (exact, order independent) and
+// derives the normalisation constants: saves a reduce launch (normalize_kernel, pass C2)
+__device__ __forceinline__ void block_fold_partials(const float2* __restrict__ part, int n_part, float& fscale, float& fshift) {
+    __shared__ float2 fold_red[16];
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    // the first four partials per thread are requested unconditionally (clamped index: a repeated partial changes
+    // nothing), so they travel together and behind whatever the caller has in flight
+    float2 p4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = (int)threadIdx.x + k * (int)blockDim.x;
+        p4[k] = part[i < n_part ? i : n_part - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mn = fminf(mn, p4[k].x);
+        mx = fmaxf(mx, p4[k].y);
+    }
+    for (int i = threadIdx.x + 4 * blockDim.x; i < n_part; i += blockDim.x) {
+        const float2 p = part[i];
+        mn = fminf(mn, p.x);
+        mx = fmaxf(mx, p.y);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, off));
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+    }
+    const int nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) fold_red[threadIdx.x >> 6] = make_float2(mn, mx);
+    __syncthreads();
+    mn = fold_red[0].x; mx = fold_red[0].y;
+    for (int w = 1; w < nw; ++w) {
+        mn = fminf(mn, fold_red[w].x);
+        mx = fmaxf(mx, fold_red[w].y);
+    }
+    minmax_to_scale_shift(mn, mx, fscale, fshift);
+}
+
 }  // namespace fdr

@@ -8,7 +8,12 @@
 namespace fdr {
 
 enum RowIn { ROW_IN_REAL = 0, ROW_IN_COMPLEX = 1 };
-enum RowOut { ROW_OUT_COMPLEX = 0, ROW_OUT_REAL_MINMAX = 1 };
+enum RowOut {
+    ROW_OUT_COMPLEX = 0,
+    ROW_OUT_REAL_MINMAX = 1,  // pass C': real plane + min/max partials
+    ROW_OUT_MINMAX_ONLY = 2,  // pass C1 (two-sweep normalisation): min/max partials, nothing stored
+    ROW_OUT_NORMALIZED = 3    // pass C2: the transform again, normalised with the folded partials and cropped on store
+};
 enum ColKind {
     COL_FWD = 0,         // forward column FFT, complex in place (PSF spectrum, fft2d)
     COL_INV = 1,         // inverse column FFT, complex in place (fft2d)
@@ -24,6 +29,7 @@ struct RowBatch {
     float2* spec[4];           // pass A output / pass C' input (panel-major spectrum)
     float* raw[4];             // pass C' output
     float2* mm_part[4];        // pass C' min/max partials
+    float* out[4];             // pass C2 output (normalised, cropped)
     int nimg;
 };
 struct NormBatch {
@@ -43,6 +49,8 @@ struct RowArgs {
     float* dst_real;  // ROW_OUT_REAL_MINMAX: M x L real plane
     float2* mm_part;  // one (min, max) partial per workgroup
     int mm_rows, mm_cols;
+    float* out;       // ROW_OUT_NORMALIZED: out_rows x out_cols result, row stride out_stride; mm_part holds n_part partials
+    int out_rows, out_cols, out_stride, n_part;
     int M;              // number of rows to transform
     size_t pstride;     // rows4 kernels: panel stride of the panel-major spectrum, in float2 elements
     int half;           // rows4 packed kernels: half (Hermitian) spectrum, N/8 panels

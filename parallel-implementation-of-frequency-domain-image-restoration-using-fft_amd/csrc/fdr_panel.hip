@@ -142,9 +142,14 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
         // that a quad of lanes owns one 128-byte line (4 rows x 4 columns of a panel): lane j of the
         // quad builds row j's four columns (32 contiguous bytes).  Every store instruction of a wave
         // then covers 16 complete lines instead of 64 scattered 8-byte pieces.
+        // The buffer of pair b = 1 is the one the transform's LAST exchange read from: a barrier has to separate those
+        // reads from this write (pair b = 0 goes to the other buffer, which the last barrier of the transform already
+        // protects).  Without it a wave that runs ahead overwrites values a slower wave is still picking up -- rows 2, 3
+        // of the group came out wrong for a few lanes' columns whenever a second stream's kernels shared the CUs.
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             float2* buf = grp_lds + ((SEQ1 + b) & 1) * St::BUF;
+            if (b == 1) __syncthreads();
 #pragma unroll
             for (int u = 0; u < Core::NUL; ++u)
 #pragma unroll
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
             }
             if (active) store4(a.dst_c + (size_t)c * a.pstride + (size_t)(r0 + j) * 4, o[0], o[1], o[2], o[3]);
         }
-    } else {
+        } else {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             float2* buf = grp_lds + ((SEQ1 + b) & 1) * St::BUF;
@@ -319,6 +324,7 @@ __global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             float2* buf = lds + ((SEQ1 + b) & 1) * St::BUF;
+            if (b == 1) __syncthreads();  // pair 1's buffer was read by the transform's last exchange (see fft_rows4_fwd_packed_kernel)
 #pragma unroll
             for (int u = 0; u < Core::NUL; ++u)
 #pragma unroll
@@ -554,20 +560,105 @@ __device__ __forceinline__ void rows4_pack_mirror(int tid, const float2 (&y)[4][
     __syncthreads();  // the transform's first exchange may overwrite either buffer
 }
 
+// Epilogue of the inverse row passes for one 4-row group (z = two packed transforms: rows r0, r0+1 and r0+2, r0+3).
+//   OUT 0 (pass C') : real plane + running min/max
+//   OUT 1 (pass C1) : running min/max only -- nothing is stored
+//   OUT 2 (pass C2) : value * fscale + fshift (two roundings, as normalize_kernel) to the cropped result, non-temporal
+template <class Core, int OUT, int V>
+__device__ __forceinline__ void rows4_inv_epilogue(const RowArgs& a, const int r0, const int tq, const float2 (&z)[2][V], const float fscale,
+                                                   const float fshift, float& mn, float& mx) {
+    constexpr int T = Core::T, L = T * V;
+    if constexpr (OUT == 0) {
+        // four row bases + the lane's column: the stores need no per-element 64-bit address arithmetic
+        float* o0 = a.dst_real + (size_t)r0 * L + tq;
+        float* o1 = o0 + L;
+        float* o2 = o1 + L;
+        float* o3 = o2 + L;
+#pragma unroll
+        for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+            for (int q = 0; q < Core::RHOL; ++q) {
+                const int s = u * Core::RHOL + q;
+                const int c = u * T + (q << Core::LOGOUT);
+                o0[c] = z[0][s].x; o1[c] = z[0][s].y; o2[c] = z[1][s].x; o3[c] = z[1][s].y;
+            }
+    }
+    if constexpr (OUT == 2) {
+        float* o0 = a.out + (size_t)r0 * a.out_stride + tq;
+        float* o1 = o0 + a.out_stride;
+        float* o2 = o1 + a.out_stride;
+        float* o3 = o2 + a.out_stride;
+        if (r0 + 3 < a.out_rows && a.out_cols >= L) {  // nothing cropped in this group
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int s = u * Core::RHOL + q;
+                    const int c = u * T + (q << Core::LOGOUT);
+                    const float p0 = z[0][s].x * fscale, p1 = z[0][s].y * fscale, p2 = z[1][s].x * fscale, p3 = z[1][s].y * fscale;
+                    __builtin_nontemporal_store(p0 + fshift, o0 + c);
+                    __builtin_nontemporal_store(p1 + fshift, o1 + c);
+                    __builtin_nontemporal_store(p2 + fshift, o2 + c);
+                    __builtin_nontemporal_store(p3 + fshift, o3 + c);
+                }
+        } else {
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int s = u * Core::RHOL + q;
+                    const int c = u * T + (q << Core::LOGOUT);
+                    if (tq + c < a.out_cols) {
+                        const float p0 = z[0][s].x * fscale, p1 = z[0][s].y * fscale, p2 = z[1][s].x * fscale, p3 = z[1][s].y * fscale;
+                        if (r0 + 0 < a.out_rows) o0[c] = p0 + fshift;
+                        if (r0 + 1 < a.out_rows) o1[c] = p1 + fshift;
+                        if (r0 + 2 < a.out_rows) o2[c] = p2 + fshift;
+                        if (r0 + 3 < a.out_rows) o3[c] = p3 + fshift;
+                    }
+                }
+        }
+    } else {
+        if (r0 + 3 < a.mm_rows && a.mm_cols >= L) {  // whole group counted (always, with FDR_NORM_PADDED)
+#pragma unroll
+            for (int s = 0; s < V; ++s) {
+                mn = fminf(fminf(mn, z[0][s].x), fminf(z[0][s].y, fminf(z[1][s].x, z[1][s].y)));
+                mx = fmaxf(fmaxf(mx, z[0][s].x), fmaxf(z[0][s].y, fmaxf(z[1][s].x, z[1][s].y)));
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int s = u * Core::RHOL + q;
+                    const int n = Core::out_index(tq, u, q);
+                    const float r[4] = {z[0][s].x, z[0][s].y, z[1][s].x, z[1][s].y};
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (r0 + b < a.mm_rows && n < a.mm_cols) {
+                            mn = fminf(mn, r[b]);
+                            mx = fmaxf(mx, r[b]);
+                        }
+                }
+        }
+    }
+}
+
 // HALF: the row spectra hold columns 0 .. N/2-1 only, column 0 packed as Y[m,0] + i Y[m,N/2] (see the forward
 // kernel); the upper half is rebuilt as the conjugate of the mirrored column (rows4_pack_mirror).
-template <int LOGL, bool HALF>
+template <int LOGL, bool HALF, int OUT = 0>
 __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_packed_kernel(const RowArgs a0,
                                                                                           const float2* __restrict__ tw_fwd) {
     RowArgs a = a0;
     if (a0.batch.nimg > 1) {  // blockIdx.y = image
         a.src_c = pick4(a0.batch.spec, blockIdx.y);
-        a.dst_real = pick4(a0.batch.raw, blockIdx.y);
+        if constexpr (OUT == 0) a.dst_real = pick4(a0.batch.raw, blockIdx.y);
+        if constexpr (OUT == 2) a.out = pick4(a0.batch.out, blockIdx.y);
         a.mm_part = pick4(a0.batch.mm_part, blockIdx.y);
     }
+    float fscale = 0.f, fshift = 0.f;
     using St = Steps<LOGL>;
     using Geo = Rows4PackGeom<LOGL>;
-    constexpr int G = Geo::G, T = St::T, L = St::L;
+    constexpr int G = Geo::G, T = St::T;
     using Core = FftCore<LOGL, 2, 2, PolicyFast>;
     __shared__ float2 lds[G * 2 * St::BUF];
     const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
@@ -583,54 +674,22 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_pa
     if constexpr (HALF && LOGL >= 5) {  // direct half from memory, mirrored half through LDS
         float2 y[4][4];
         rows4_load_direct<LOGL, Core>(a, rr, tid, y);
+        // pass C2: the partials are folded BEHIND the group's own loads (a workgroup lives for one group here: a fold in
+        // front of them adds its full memory latency to every workgroup -- measured +6 us per 4096^2 image)
+        if constexpr (OUT == 2) block_fold_partials(a.mm_part, a.n_part, fscale, fshift);
         rows4_pack_mirror<LOGL, Core>(tid, y, z, lds + g * 2 * St::BUF);
     } else {
         float2 y[4][8];
         rows4_load_raw<LOGL, HALF, Core>(a, rr, tid, y);
+        if constexpr (OUT == 2) block_fold_partials(a.mm_part, a.n_part, fscale, fshift);
         rows4_pack<LOGL, HALF, Core>(tid, y, z);
     }
 
     Core::template run<0, true>(z, lds + g * 2 * St::BUF, tw_fwd, bases, tid);
 
     float mn = __builtin_inff(), mx = -__builtin_inff();
-    if (active) {
-        // four row bases + the lane's column: the stores need no per-element 64-bit address arithmetic
-        float* o0 = a.dst_real + (size_t)r0 * L + tid;
-        float* o1 = o0 + L;
-        float* o2 = o1 + L;
-        float* o3 = o2 + L;
-#pragma unroll
-        for (int u = 0; u < Core::NUL; ++u)
-#pragma unroll
-            for (int q = 0; q < Core::RHOL; ++q) {
-                const int s = u * Core::RHOL + q;
-                const int c = u * T + (q << Core::LOGOUT);
-                o0[c] = z[0][s].x; o1[c] = z[0][s].y; o2[c] = z[1][s].x; o3[c] = z[1][s].y;
-            }
-        if (r0 + 3 < a.mm_rows && a.mm_cols >= L) {  // whole group counted (always, with FDR_NORM_PADDED)
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                mn = fminf(fminf(mn, z[0][s].x), fminf(z[0][s].y, fminf(z[1][s].x, z[1][s].y)));
-                mx = fmaxf(fmaxf(mx, z[0][s].x), fmaxf(z[0][s].y, fmaxf(z[1][s].x, z[1][s].y)));
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < Core::NUL; ++u)
-#pragma unroll
-                for (int q = 0; q < Core::RHOL; ++q) {
-                    const int s = u * Core::RHOL + q;
-                    const int n = Core::out_index(tid, u, q);
-                    const float r[4] = {z[0][s].x, z[0][s].y, z[1][s].x, z[1][s].y};
-#pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        if (r0 + b < a.mm_rows && n < a.mm_cols) {
-                            mn = fminf(mn, r[b]);
-                            mx = fmaxf(mx, r[b]);
-                        }
-                }
-        }
-    }
-    block_minmax_store(mn, mx, a.mm_part, (int)blockIdx.x);
+    if (active) rows4_inv_epilogue<Core, OUT, 8>(a, r0, tid, z, fscale, fshift, mn, mx);
+    if constexpr (OUT != 2) block_minmax_store(mn, mx, a.mm_part, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -638,17 +697,20 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_pa
 // requested (rows4_load_raw into y) before the current group is transformed and stored.  grid (workgroups, images):
 // a workgroup stays inside one image, so it writes ONE (min, max) partial for all its groups.
 // ---------------------------------------------------------------------------------------------
-template <int LOGL, int LOGV, bool HALF>
+template <int LOGL, int LOGV, bool HALF, int OUT = 0>
 __global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<LOGL, LOGV>::WAVES_PER_SIMD)) void fft_rows4_inv_pers_kernel(
     const RowArgs a0, const float2* __restrict__ tw_fwd, const int ngroups) {
     RowArgs a = a0;
     if (a0.batch.nimg > 1) {  // blockIdx.y = image
         a.src_c = pick4(a0.batch.spec, blockIdx.y);
-        a.dst_real = pick4(a0.batch.raw, blockIdx.y);
+        if constexpr (OUT == 0) a.dst_real = pick4(a0.batch.raw, blockIdx.y);
+        if constexpr (OUT == 2) a.out = pick4(a0.batch.out, blockIdx.y);
         a.mm_part = pick4(a0.batch.mm_part, blockIdx.y);
     }
+    float fscale = 0.f, fshift = 0.f;
+    if constexpr (OUT == 2) block_fold_partials(a.mm_part, a.n_part, fscale, fshift);
     using St = Steps<LOGL, LOGV>;
-    constexpr int T = St::T, L = St::L, V = St::V;
+    constexpr int V = St::V;
     using Core = FftCore<LOGL, 2, 2, PolicyFast, LOGV, (St::lr(0) == 1 && FDR_SWAP0)>;  // 8192 points: wave-local first exchange
     __shared__ float2 lds[2 * St::BUF];
     const int tid = Core::thread_index(threadIdx.x);
@@ -678,40 +740,7 @@ __global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<
         const int r0 = g * 4;
         int tq = tid;  // opaque copy: keeps the store addresses from being hoisted out of the group loop
         asm volatile("" : "+v"(tq));
-        float* o0 = a.dst_real + (size_t)r0 * L + tq;
-        float* o1 = o0 + L;
-        float* o2 = o1 + L;
-        float* o3 = o2 + L;
-#pragma unroll
-        for (int u = 0; u < Core::NUL; ++u)
-#pragma unroll
-            for (int q = 0; q < Core::RHOL; ++q) {
-                const int s = u * Core::RHOL + q;
-                const int c = u * T + (q << Core::LOGOUT);
-                o0[c] = z[0][s].x; o1[c] = z[0][s].y; o2[c] = z[1][s].x; o3[c] = z[1][s].y;
-            }
-        if (r0 + 3 < a.mm_rows && a.mm_cols >= L) {  // whole group counted (always, with FDR_NORM_PADDED)
-#pragma unroll
-            for (int s = 0; s < V; ++s) {
-                mn = fminf(fminf(mn, z[0][s].x), fminf(z[0][s].y, fminf(z[1][s].x, z[1][s].y)));
-                mx = fmaxf(fmaxf(mx, z[0][s].x), fmaxf(z[0][s].y, fmaxf(z[1][s].x, z[1][s].y)));
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < Core::NUL; ++u)
-#pragma unroll
-                for (int q = 0; q < Core::RHOL; ++q) {
-                    const int s = u * Core::RHOL + q;
-                    const int n = Core::out_index(tq, u, q);
-                    const float r[4] = {z[0][s].x, z[0][s].y, z[1][s].x, z[1][s].y};
-#pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        if (r0 + b < a.mm_rows && n < a.mm_cols) {
-                            mn = fminf(mn, r[b]);
-                            mx = fmaxf(mx, r[b]);
-                        }
-                }
-        }
+        rows4_inv_epilogue<Core, OUT, V>(a, r0, tq, z, fscale, fshift, mn, mx);
     };
     // loop shape as in fft_rows4_fwd_pers_kernel: the prefetch is waited for at the bottom (pack), behind the stores
     int grp = blockIdx.x;  // (the grid never exceeds the number of groups)
@@ -737,7 +766,7 @@ __global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<
         pack();
         grp = gn;
     }
-    block_minmax_store(mn, mx, a.mm_part, (int)blockIdx.x);
+    if constexpr (OUT != 2) block_minmax_store(mn, mx, a.mm_part, (int)blockIdx.x);
 }
 
 // persistent pass C' is used when a workgroup gets more than one group (else there is nothing to overlap); always for
@@ -1012,6 +1041,23 @@ __global__ __launch_bounds__(256) void normalize_fixup_kernel(const RowArgs a, c
 #ifndef FDR_ROWS_PERSISTENT
 #define FDR_ROWS_PERSISTENT 1
 #endif
+template <int LOGL, int OUT>
+static hipError_t launch_rows4_inv_t(const RowArgs& a, const float2* tw, hipStream_t s, int groups, int nimg, dim3 grid, dim3 block) {
+    if constexpr (LOGL >= FDR_ROWS_PERS_MIN_LOG && FDR_ROWS_PERSISTENT) {
+        constexpr int LOGV = LOGL >= 13 ? 4 : (LOGL == 12 ? FDR_ROWS12_LOGV : 3);
+        using PG = RowsPersGeom<LOGL, LOGV>;
+        if (rows4_inv_use_pers<LOGL>(a.M, a.num_cu, nimg)) {
+            const dim3 pgrid(rows4_inv_pers_grid<LOGL>(a.M, a.num_cu, nimg), nimg), pblock(PG::THREADS);
+            if (a.half) hipLaunchKernelGGL((fft_rows4_inv_pers_kernel<LOGL, LOGV, true, OUT>), pgrid, pblock, 0, s, a, tw, groups);
+            else if constexpr (OUT == 0) hipLaunchKernelGGL((fft_rows4_inv_pers_kernel<LOGL, LOGV, false, 0>), pgrid, pblock, 0, s, a, tw, groups);
+            return hipGetLastError();
+        }
+    }
+    if (a.half) hipLaunchKernelGGL((fft_rows4_inv_packed_kernel<LOGL, true, OUT>), grid, block, 0, s, a, tw);
+    else if constexpr (OUT == 0) hipLaunchKernelGGL((fft_rows4_inv_packed_kernel<LOGL, false, 0>), grid, block, 0, s, a, tw);
+    return hipGetLastError();
+}
+
 template <int LOGL>
 static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const float2* tw, hipStream_t s) {
     using Geo = Rows4PackGeom<LOGL>;
@@ -1044,18 +1090,13 @@ static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const f
         if (a.half) hipLaunchKernelGGL((fft_rows4_fwd_packed_kernel<LOGL, true>), grid, block, 0, s, a, tw);
         else hipLaunchKernelGGL((fft_rows4_fwd_packed_kernel<LOGL, false>), grid, block, 0, s, a, tw);
     } else if (in == ROW_IN_COMPLEX && out == ROW_OUT_REAL_MINMAX) {
-        if constexpr (LOGL >= FDR_ROWS_PERS_MIN_LOG && FDR_ROWS_PERSISTENT) {
-            constexpr int LOGV = LOGL >= 13 ? 4 : (LOGL == 12 ? FDR_ROWS12_LOGV : 3);
-            using PG = RowsPersGeom<LOGL, LOGV>;
-            if (rows4_inv_use_pers<LOGL>(a.M, a.num_cu, nimg)) {
-                const dim3 pgrid(rows4_inv_pers_grid<LOGL>(a.M, a.num_cu, nimg), nimg), pblock(PG::THREADS);
-                if (a.half) hipLaunchKernelGGL((fft_rows4_inv_pers_kernel<LOGL, LOGV, true>), pgrid, pblock, 0, s, a, tw, groups);
-                else hipLaunchKernelGGL((fft_rows4_inv_pers_kernel<LOGL, LOGV, false>), pgrid, pblock, 0, s, a, tw, groups);
-                return hipGetLastError();
-            }
-        }
-        if (a.half) hipLaunchKernelGGL((fft_rows4_inv_packed_kernel<LOGL, true>), grid, block, 0, s, a, tw);
-        else hipLaunchKernelGGL((fft_rows4_inv_packed_kernel<LOGL, false>), grid, block, 0, s, a, tw);
+        return launch_rows4_inv_t<LOGL, 0>(a, tw, s, groups, nimg, grid, block);
+    } else if (in == ROW_IN_COMPLEX && out == ROW_OUT_MINMAX_ONLY) {
+        if (!a.half) return hipErrorInvalidValue;  // two-sweep normalisation: half-spectrum path only
+        return launch_rows4_inv_t<LOGL, 1>(a, tw, s, groups, nimg, grid, block);
+    } else if (in == ROW_IN_COMPLEX && out == ROW_OUT_NORMALIZED) {
+        if (!a.half) return hipErrorInvalidValue;
+        return launch_rows4_inv_t<LOGL, 2>(a, tw, s, groups, nimg, grid, block);
     } else {
         return hipErrorInvalidValue;
     }

@@ -240,6 +240,39 @@ def test_fused_normalise_pass_equals_two_pass(fdr, oracle, shape, spin_limit):
                 _assert_same(p.wiener(img, norm_area=area), q.wiener(img, norm_area=area), "fused vs two-pass, area %d" % area)
 
 
+@pytest.mark.parametrize("shape", [(32, 32), (30, 50), (100, 200), (256, 256), (500, 1000), (1024, 1024), (2000, 2048), (600, 4096), (37, 8100)])
+def test_two_sweep_normalisation_equals_raw_plane_passes(fdr, oracle, shape):
+    """FDR_OPT_TWO_SWEEP_NORM: passes C1 (inverse rows, min/max only) + C2 (inverse rows again, normalised and cropped on
+    store) must give the bits of passes C' (raw plane) + E (normalise): both settings, both normalisation areas, single
+    images and grouped launches with a tail."""
+    import torch
+    rows, cols = shape
+    psf = oracle.motion_blur_kernel(15, 30.0)
+    B = 5
+    host = np.stack([_image(oracle, rows, cols, 900 + i) for i in range(B)])
+    M, N = fdr.nextPowerOfTwo(rows), fdr.nextPowerOfTwo(cols)
+    d_in = torch.from_numpy(host).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    with fdr.Plan(M, N, fdr.MODE_FAST) as p, fdr.Plan(M, N, fdr.MODE_FAST) as q:
+        p.set_option(fdr.OPT_TWO_SWEEP_NORM, 1)
+        q.set_option(fdr.OPT_TWO_SWEEP_NORM, 0)
+        p.set_psf(psf, 0.01)
+        q.set_psf(psf, 0.01)
+        for area in (fdr.NORM_PADDED, fdr.NORM_CROPPED):
+            _assert_same(p.wiener(host[0], norm_area=area), q.wiener(host[0], norm_area=area), "two-sweep vs raw plane, area %d" % area)
+            for nstreams, group in ((1, 4), (2, 2), (1, 3)):
+                outs = []
+                for plan in (p, q):
+                    d_o = torch.full_like(d_in, -1.0)
+                    plan.set_batching(nstreams, group)
+                    plan.wiener_batch_dev(d_in.data_ptr(), rows * cols, B, rows, cols, cols, d_o.data_ptr(), rows * cols, cols, area, stream=s)
+                    torch.cuda.synchronize()
+                    outs.append(d_o.cpu().numpy())
+                _assert_same(outs[0], outs[1], "two-sweep vs raw plane, batch %dx%d, area %d" % (nstreams, group, area))
+        ref = oracle.serial_channel(host[0], psf, 0.01)
+        assert float(np.max(np.abs(p.wiener(host[0]) - ref))) <= 1e-4
+
+
 @pytest.mark.parametrize("shape", [(1024, 64), (2000, 100), (4096, 128), (8192, 64), (1024, 1024), (512, 64), (300, 2048), (64, 8192)])
 def test_tall_and_wide_shapes_within_tolerance(fdr, oracle, shape):
     """Pass B' with 16 values per thread (columns of 1024 points and more) and the persistent radix-8 kernel (shorter
@@ -380,6 +413,43 @@ def test_grouped_long_column_launches_equal_one_by_one(fdr, oracle, shape):
             assert np.count_nonzero(~(d_g.cpu().numpy() == one)) == 0, (nstreams, group)
     ref = oracle.serial_channel(host[5], psf, 0.01)
     assert float(np.max(np.abs(one[5] - ref))) <= 1e-4
+
+
+@pytest.mark.parametrize("shape,mode_name,flags_name", [((1024, 4096), "MODE_FAST", None), ((600, 4096), "MODE_FAST", None),
+                                                        ((1024, 4096), "MODE_FAST", "FLAG_FULL_SPECTRUM"), ((2048, 2048), "MODE_FAST", None),
+                                                        ((600, 4096), "MODE_PARITY", None)])
+def test_overlapping_streams_equal_one_by_one_every_image(fdr, oracle, shape, mode_name, flags_name):
+    """Regression (round 2): pass A wrote the second packed spectrum into the LDS buffer the transform's last exchange was
+    still being read from -- a race that only showed when a second stream's kernels shared the CUs (up to half of the
+    runs had an image with two wrong rows per affected 4-row group; image 0 never).  Every image of a batch, every
+    batching, several repetitions, against the one-by-one result -- bit for bit."""
+    import torch
+    rows, cols = shape
+    B, reps = 8, 6
+    M, N = fdr.nextPowerOfTwo(rows), fdr.nextPowerOfTwo(cols)
+    host = np.stack([_image(oracle, rows, cols, 700 + i) for i in range(B)])
+    d_in = torch.from_numpy(host).cuda()
+    d_o = torch.empty_like(d_in)
+    s = torch.cuda.current_stream().cuda_stream
+    flags = getattr(fdr, flags_name) if flags_name else 0
+    mode = getattr(fdr, mode_name)
+    sweeps = (0, 1) if (mode == fdr.MODE_FAST and not flags) else (0,)
+    for two in sweeps:
+        with fdr.Plan(M, N, mode, flags=flags) as p:
+            p.set_option(fdr.OPT_TWO_SWEEP_NORM, two)
+            p.set_psf_motion(15, 30.0, 0.01)
+            one = np.stack([p.wiener(host[i]) for i in range(B)])
+            for ns, gr in ((2, 1), (3, 1), (2, 2), (3, 2), (2, 4)):
+                if mode == fdr.MODE_PARITY and gr > 1:
+                    continue
+                p.set_batching(ns, gr)
+                for rep in range(reps):
+                    d_o.fill_(-1.0)
+                    p.wiener_batch_dev(d_in.data_ptr(), rows * cols, B, rows, cols, cols, d_o.data_ptr(), rows * cols, cols, stream=s)
+                    torch.cuda.synchronize()
+                    o = d_o.cpu().numpy()
+                    bad = [i for i in range(B) if np.count_nonzero(o[i] != one[i])]
+                    assert not bad, "two_sweep %d, %d streams x %d, repetition %d: images %s differ from the one-by-one result" % (two, ns, gr, rep, bad)
 
 
 @pytest.mark.parametrize("pinned", [False, True])

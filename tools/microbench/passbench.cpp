@@ -1,7 +1,7 @@
 // passbench -- torch-free timing of the restoration passes through the C ABI of a libfdr build chosen at run time
 // (dlopen), so that one GPU call can compare several builds and sizes without paying a Python / torch start-up each.
 //
-//   passbench <libfdr.so> <size> [batch=8] [steps=10] [streams=1] [group=1] [mode=1] [flags=0]
+//   passbench <libfdr.so> <size> [batch=8] [steps=10] [streams=1] [group=1] [mode=1] [flags=0] [two_sweep=-1 (library default)]
 //
 // Prints: per-pass mean device time (hipEvent pairs, one stream, un-overlapped) with the fraction of the 8 TB/s HBM
 // peak its algorithmic bytes give, then the batched throughput with the requested streams / group (median of 5).
@@ -28,6 +28,7 @@ struct Api {
     int (*profile)(fdr_plan*, int);
     int (*pass_times)(fdr_plan*, int*, float*, const char**, int*);
     int (*batch_dev)(fdr_plan*, const float*, size_t, int, int, int, int, float*, size_t, int, int, void*);
+    int (*set_option)(fdr_plan*, int, long long);
     const char* (*last_error)(void);
 };
 #define FCK(x) do { int r_ = (x); if (r_ != 0) { std::printf("fdr error %d: %s at %s:%d\n", r_, api.last_error(), __FILE__, __LINE__); std::exit(1); } } while (0)
@@ -36,6 +37,8 @@ static double bytes_per_px(const std::string& name, bool half) {
     if (name.rfind("A ", 0) == 0) return half ? 8 : 12;
     if (name.rfind("B'", 0) == 0) return half ? 12 : 24;
     if (name.rfind("C'E", 0) == 0) return half ? 8 : 12;
+    if (name.rfind("C1", 0) == 0) return 4;
+    if (name.rfind("C2", 0) == 0) return 8;
     if (name.rfind("C'", 0) == 0) return half ? 8 : 12;
     if (name.rfind("E ", 0) == 0) return 8;
     if (name.rfind("B ", 0) == 0) return 24;
@@ -54,6 +57,7 @@ int main(int argc, char** argv) {
     const int group = argc > 6 ? std::atoi(argv[6]) : 1;
     const int mode = argc > 7 ? std::atoi(argv[7]) : 1;
     const unsigned flags = argc > 8 ? (unsigned)std::strtoul(argv[8], nullptr, 0) : 0u;
+    const int two_sweep = argc > 9 ? std::atoi(argv[9]) : -1;
     void* h = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
     if (!h) { std::printf("dlopen %s: %s\n", libpath, dlerror()); return 1; }
     Api api;
@@ -61,6 +65,7 @@ int main(int argc, char** argv) {
     SYM(plan_create, "fdr_plan_create"); SYM(plan_destroy, "fdr_plan_destroy"); SYM(set_psf_motion, "fdr_set_psf_motion");
     SYM(synth, "fdr_synth_image_dev"); SYM(set_batching, "fdr_plan_set_batching"); SYM(profile, "fdr_plan_profile");
     SYM(pass_times, "fdr_plan_pass_times"); SYM(batch_dev, "fdr_wiener_batch_f32_dev"); SYM(last_error, "fdr_last_error");
+    SYM(set_option, "fdr_plan_set_option");
 
     const size_t P = (size_t)S * S;
     float *d_in = nullptr, *d_out = nullptr;
@@ -70,6 +75,7 @@ int main(int argc, char** argv) {
     CK(hipStreamCreate(&st));
     fdr_plan* plan = nullptr;
     FCK(api.plan_create(0, S, S, mode, flags, &plan));
+    if (two_sweep >= 0) FCK(api.set_option(plan, 2 /* FDR_OPT_TWO_SWEEP_NORM */, two_sweep));
     FCK(api.set_psf_motion(plan, 50, 30.0, 0.01f, st));
     FCK(api.synth(0, 0x5EED0003ull, 0, P * B, d_in, st));
     CK(hipStreamSynchronize(st));
@@ -88,7 +94,7 @@ int main(int argc, char** argv) {
     FCK(api.pass_times(plan, &n, ms, names, launches));
     FCK(api.profile(plan, 0));
     double sum_us = 0;
-    std::printf("== %s  size %d  batch %d  steps %d  mode %d flags %u\n", libpath, S, B, steps, mode, flags);
+    std::printf("== %s  size %d  batch %d  steps %d  mode %d flags %u two_sweep %d\n", libpath, S, B, steps, mode, flags, two_sweep);
     for (int i = 0; i < n; ++i) {
         std::string nm = names[i];
         int nimg = 1;
