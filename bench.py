@@ -42,6 +42,8 @@ PASS_BYTES = {
     "half": {
         "A rows: pad+FFT (real->complex)": 8, "B' cols: FFT*W*IFFT": 12, "C' rows: IFFT+real+minmax": 8, "E normalize+crop": 8,
         "C'E rows: IFFT+minmax+normalize+crop (fused)": 8, "E' fixup (no-op unless a wait timed out)": 0,
+        # two-sweep normalisation (default): the inverse row pass runs twice, no raw real plane
+        "C1 rows: IFFT+minmax": 4, "C2 rows: IFFT+normalize+crop": 8,
     },
 }
 PIPELINE_BYTES = {("fast", "half"): 36, ("fast", "full"): 56, ("parity", "full"): 72}
@@ -66,6 +68,7 @@ def parse():
     ap.add_argument("--total-batch", type=int, default=0,
                     help="strong scaling: a FIXED batch of T images per step sharded over the ranks by calculate_distribution "
                          "(fft/fft_mpi.cpp:89-100), e.g. BASELINE config 5: --size 2048 --total-batch 512; 0 = weak scaling with --batch per GPU")
+    ap.add_argument("--raw-plane", action="store_true", help="passes C' + E (raw real plane, 36 B/pixel) instead of the two-sweep C1 + C2 (32 B/pixel)")
     ap.add_argument("--no-psf-recompute", action="store_true", help="skip the second figure (PSF spectrum rebuilt per image)")
     return ap.parse_args()
 
@@ -148,6 +151,8 @@ def main():
         flags |= fdr.FLAG_FUSED_NORM
     spectrum = "half" if (args.mode == "fast" and not (flags & fdr.FLAG_FULL_SPECTRUM) and S >= 32) else "full"
     plan = fdr.Plan(S, S, mode, device=local_rank, flags=flags)
+    if args.raw_plane:
+        plan.set_option(fdr.OPT_TWO_SWEEP_NORM, 0)
     stream = torch.cuda.current_stream().cuda_stream
     # measured best (tools/microbench/passbench, profiles/README.md): every pass runs 10-17 % faster per image when a
     # launch covers more than one image (launch gaps and the ramp-up / drain of a grid amortise; in pass B' the

@@ -98,7 +98,7 @@ int fdr_plan_dims(const fdr_plan* plan, int* M, int* N, int* mode);
 #define FDR_OPT_TWO_SWEEP_NORM 2   /* fast mode, half spectrum: 1 = the inverse row pass runs twice (min/max only, then
                                       again with the normalisation applied on store) instead of writing a raw real plane
                                       that a normalise pass reads back: 12 instead of 16 bytes per pixel for the last two
-                                      passes, same bits.  0 = passes C' + E.  Default: see DESIGN.md section 5. */
+                                      passes, same bits (default).  0 = passes C' + E. */
 int fdr_plan_set_option(fdr_plan* plan, int option, long long value);
 
 /* -- PSF generation: utils.hpp:15-24 motionBlurKernel(size, angle) ------------------- */

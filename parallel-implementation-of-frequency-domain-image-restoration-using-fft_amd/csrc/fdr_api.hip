@@ -166,7 +166,7 @@ struct fdr_plan {
     // fused pass C'+E (fast panel path, half spectrum, images of at most 4 row groups per CU)
     bool fused_norm = false; int fused_R = 0, fused_nwg = 0;
     unsigned spin_limit = 20000;     // sweeps (~0.5 us each) before a waiting workgroup falls back
-    bool two_sweep = false;          // FDR_OPT_TWO_SWEEP_NORM: passes C1 + C2 instead of C' + E (fast half-spectrum path)
+    bool two_sweep = true;           // FDR_OPT_TWO_SWEEP_NORM: passes C1 + C2 instead of C' + E (fast half-spectrum path)
     hipEvent_t fused_done = nullptr; // fused launches of one plan never overlap: each holds every CU while it waits
     bool fused_recorded = false;
 };

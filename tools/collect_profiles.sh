@@ -15,6 +15,8 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 make -s -C tools/microbench membench 2>/dev/null || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/microbench/membench tools/microbench/membench.hip
 python3 bench.py > $OUT/bench_default.log 2>&1; echo "bench_default rc=$?" >> $OUT/status.txt
 grep '^{' $OUT/bench_default.log | tail -n 1 > $OUT/bench_line.json
+# the same with passes C' + E (raw real plane, 36 B/pixel) instead of the default two-sweep C1 + C2 (32 B/pixel)
+python3 bench.py --raw-plane --no-cpu-baseline --no-psf-recompute > $OUT/bench_raw_plane.log 2>&1; echo "bench_raw_plane rc=$?" >> $OUT/status.txt
 for S in 4096 8192; do
   if [ $S = 8192 ]; then B="--batch 12 --steps 6 --warmup 2"; else B="--batch 48 --steps 10 --warmup 3"; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$S -o kt -- python3 bench.py --size $S $B --streams 1 --repeats 1 --no-cpu-baseline --no-psf-recompute > $OUT/kt_$S.log 2>&1; echo "kt_$S rc=$?" >> $OUT/status.txt

@@ -70,6 +70,9 @@ def main():
         traffic, rows = {}, []
         for kname, vals in fe.items():
             for key, pname in PASS_OF.items():
+                if key.startswith("fft_rows4_inv_"):  # last template argument: 0 raw plane (C'), 1 min/max only (C1), 2 normalised (C2)
+                    if ", 1>(" in kname: pname = "C1 rows: IFFT+minmax"
+                    elif ", 2>(" in kname: pname = "C2 rows: IFFT+normalize+crop"
                 if len(vals) >= 2 and key in kname and ("<%d>" % lg in kname or "<%d," % lg in kname or key == "normalize_kernel"):  # (single dispatches: the PSF's own passes)
                     rd = statistics.median(vals) * round(fetch_factor) * 1024.0
                     wv = [v for k, v in wr.items() if k == kname]
@@ -87,7 +90,7 @@ def main():
             print(size, r[0], "read %.1f MB write %.1f MB" % (r[5] / 1e6, r[6] / 1e6))
     json.dump(tj, open(tj_path, "w"), indent=1, sort_keys=True)
     for name in ("bench_line.json", "bench_line_streams1_4096.json", "bench_line_streams1_8192.json", "two_rank_weak.log", "two_rank_strong.log",
-                 "config5_one_gpu.log", "config2_size.log", "config4_size.log", "status.txt"):
+                 "config5_one_gpu.log", "config2_size.log", "config4_size.log", "bench_raw_plane.log", "status.txt"):
         pth = os.path.join(src, name)
         if os.path.exists(pth):
             txt = open(pth).read()
