@@ -99,6 +99,10 @@ int fdr_plan_dims(const fdr_plan* plan, int* M, int* N, int* mode);
                                       again with the normalisation applied on store) instead of writing a raw real plane
                                       that a normalise pass reads back: 12 instead of 16 bytes per pixel for the last two
                                       passes, same bits (default).  0 = passes C' + E. */
+#define FDR_OPT_BATCH_GRAPH 3      /* 1 = fdr_wiener_batch_f32_dev captures its launches (fork, every pass of every group on
+                                      the internal streams, join) as a hipGraph on first use and replays it while the call's
+                                      arguments stay the same: for small images, whose batches are bound by the host's
+                                      launch rate.  0 (default) = plain launches. */
 int fdr_plan_set_option(fdr_plan* plan, int option, long long value);
 
 /* -- PSF generation: utils.hpp:15-24 motionBlurKernel(size, angle) ------------------- */

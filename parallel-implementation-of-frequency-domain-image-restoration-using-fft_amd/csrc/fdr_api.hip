@@ -167,6 +167,21 @@ struct fdr_plan {
     bool fused_norm = false; int fused_R = 0, fused_nwg = 0;
     unsigned spin_limit = 20000;     // sweeps (~0.5 us each) before a waiting workgroup falls back
     bool two_sweep = true;           // FDR_OPT_TWO_SWEEP_NORM: passes C1 + C2 instead of C' + E (fast half-spectrum path)
+    // FDR_OPT_BATCH_GRAPH: the launches of one fdr_wiener_batch_f32_dev call (fork, every pass of every group on the
+    // internal streams, join) captured once as a hipGraph and replayed while the call's arguments stay the same
+    struct GraphKey {
+        const float* in; float* out; size_t in_pitch, out_pitch; int count, rows, cols, stride, out_stride, norm_area, nstreams, group;
+        bool two_sweep; float K;
+        bool operator==(const GraphKey& o) const {
+            return in == o.in && out == o.out && in_pitch == o.in_pitch && out_pitch == o.out_pitch && count == o.count && rows == o.rows &&
+                   cols == o.cols && stride == o.stride && out_stride == o.out_stride && norm_area == o.norm_area && nstreams == o.nstreams &&
+                   group == o.group && two_sweep == o.two_sweep && K == o.K;
+        }
+    };
+    bool batch_graph = false;
+    hipGraphExec_t graph_exec = nullptr;
+    GraphKey graph_key{};
+    hipStream_t cap_stream = nullptr;
     hipEvent_t fused_done = nullptr; // fused launches of one plan never overlap: each holds every CU while it waits
     bool fused_recorded = false;
 };
@@ -695,6 +710,8 @@ int fdr_plan_destroy(fdr_plan* p) {
         if (p->slots[k].done) (void)hipEventDestroy(p->slots[k].done);
         (void)hipFree(p->slots[k].gran); (void)hipFree(p->slots[k].fallback);
     }
+    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+    if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     if (p->fork) (void)hipEventDestroy(p->fork);
     if (p->fused_done) (void)hipEventDestroy(p->fused_done);
     (void)hipFree(p->tw_row_f); (void)hipFree(p->tw_row_i); (void)hipFree(p->tw_col_f); (void)hipFree(p->tw_col_i);
@@ -721,6 +738,10 @@ int fdr_plan_dims(const fdr_plan* p, int* M, int* N, int* mode) {
 int fdr_plan_set_option(fdr_plan* p, int option, long long value) {
     if (!p) return fail(FDR_ERR_ARG, "fdr_plan_set_option: null plan");
     switch (option) {
+        case FDR_OPT_BATCH_GRAPH:
+            if (value != 0 && value != 1) return fail(FDR_ERR_ARG, "fdr_plan_set_option: FDR_OPT_BATCH_GRAPH takes 0 or 1");
+            p->batch_graph = value != 0;
+            return FDR_OK;
         case FDR_OPT_TWO_SWEEP_NORM:
             if (value != 0 && value != 1) return fail(FDR_ERR_ARG, "fdr_plan_set_option: FDR_OPT_TWO_SWEEP_NORM takes 0 or 1");
             p->two_sweep = value != 0;
@@ -803,6 +824,14 @@ int fdr_wiener_f32_dev(fdr_plan* p, const float* d_img, int rows, int cols, int 
     return wiener_dev_impl(p, p->slots[0], d_img, rows, cols, stride, d_out, out_stride, norm_area, (hipStream_t)stream);
 }
 
+}  // extern "C"
+namespace {
+// fork, every pass of every group, join -- all relative to `us` (the caller's stream, or the capturing stream)
+int batch_enqueue(fdr_plan* p, const float* d_imgs, size_t img_pitch, int count, int rows, int cols, int stride, float* d_out,
+                  size_t out_pitch, int out_stride, int norm_area, hipStream_t us);
+}
+extern "C" {
+
 int fdr_wiener_batch_f32_dev(fdr_plan* p, const float* d_imgs, size_t img_pitch, int count, int rows, int cols, int stride,
                              float* d_out, size_t out_pitch, int out_stride, int norm_area, void* stream) {
     if (!p) return fail(FDR_ERR_ARG, "fdr_wiener_batch_f32_dev: null plan");
@@ -812,6 +841,36 @@ int fdr_wiener_batch_f32_dev(fdr_plan* p, const float* d_imgs, size_t img_pitch,
     hipStream_t us = (hipStream_t)stream;
     int rc = check_image_args(p, d_imgs, rows, cols, stride, d_out, out_stride);
     if (rc != FDR_OK) return rc;
+    // graph replay: launch-bound batches (small images) pay one graph launch instead of 4 kernel launches per group.
+    // Not with per-kernel profiling (host-side event pairs) nor with the fused C'E pass (allocates on first use).
+    if (p->batch_graph && p->panel && !p->timer.enabled && !p->fused_norm) {
+        const fdr_plan::GraphKey key{d_imgs, d_out, img_pitch, out_pitch, count, rows, cols, stride, out_stride, norm_area, p->nstreams, p->group,
+                                     p->two_sweep, p->K};
+        if (!(p->graph_exec && key == p->graph_key)) {
+            if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+            if (!p->cap_stream) FDR_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
+            FDR_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal));
+            rc = batch_enqueue(p, d_imgs, img_pitch, count, rows, cols, stride, d_out, out_pitch, out_stride, norm_area, p->cap_stream);
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(p->cap_stream, &g);  // (always: the stream has to leave capture mode)
+            if (rc != FDR_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+            FDR_HIP(e);
+            const hipError_t ei = hipGraphInstantiate(&p->graph_exec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (ei != hipSuccess) { p->graph_exec = nullptr; FDR_HIP(ei); }
+            p->graph_key = key;
+        }
+        FDR_HIP(hipGraphLaunch(p->graph_exec, us));
+        return FDR_OK;
+    }
+    return batch_enqueue(p, d_imgs, img_pitch, count, rows, cols, stride, d_out, out_pitch, out_stride, norm_area, us);
+}
+
+}  // extern "C"
+namespace {
+int batch_enqueue(fdr_plan* p, const float* d_imgs, size_t img_pitch, int count, int rows, int cols, int stride, float* d_out,
+                  size_t out_pitch, int out_stride, int norm_area, hipStream_t us) {
+    int rc = FDR_OK;
     const int mm_rows = norm_area == FDR_NORM_PADDED ? p->M : rows;
     const int mm_cols = norm_area == FDR_NORM_PADDED ? p->N : cols;
     const int group = p->panel ? p->group : 1;
@@ -862,6 +921,8 @@ int fdr_wiener_batch_f32_dev(fdr_plan* p, const float* d_imgs, size_t img_pitch,
     }
     return rc;
 }
+}  // namespace
+extern "C" {
 
 int fdr_plan_set_batching(fdr_plan* p, int nstreams, int group) {
     if (!p) return fail(FDR_ERR_ARG, "fdr_plan_set_batching: null plan");

@@ -452,6 +452,49 @@ def test_overlapping_streams_equal_one_by_one_every_image(fdr, oracle, shape, mo
                     assert not bad, "two_sweep %d, %d streams x %d, repetition %d: images %s differ from the one-by-one result" % (two, ns, gr, rep, bad)
 
 
+@pytest.mark.parametrize("shape", [(100, 200), (512, 512), (1000, 1024)])
+def test_batch_graph_replay_equals_plain_launches(fdr, oracle, shape):
+    """FDR_OPT_BATCH_GRAPH: the batch call's launches captured as a hipGraph and replayed -- same bits as plain launches;
+    the graph is rebuilt when the arguments change (other output buffer, other count, other batching) and follows a new
+    PSF (the filter is read at run time, not captured by value)."""
+    import torch
+    rows, cols = shape
+    B = 9
+    M, N = fdr.nextPowerOfTwo(rows), fdr.nextPowerOfTwo(cols)
+    host = np.stack([_image(oracle, rows, cols, 500 + i) for i in range(B)])
+    d_in = torch.from_numpy(host).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    with fdr.Plan(M, N, fdr.MODE_FAST) as p, fdr.Plan(M, N, fdr.MODE_FAST) as q:
+        p.set_option(fdr.OPT_BATCH_GRAPH, 1)
+        for plan in (p, q):
+            plan.set_psf_motion(15, 30.0, 0.01)
+            plan.set_batching(2, 4)
+
+        def both(count, batching=None):
+            outs = []
+            for plan in (p, q):
+                if batching:
+                    plan.set_batching(*batching)
+                d_o = torch.full_like(d_in, -1.0)
+                for _ in range(3 if plan is p else 1):  # capture, then two replays into the same buffer
+                    plan.wiener_batch_dev(d_in.data_ptr(), rows * cols, count, rows, cols, cols, d_o.data_ptr(), rows * cols, cols, stream=s)
+                torch.cuda.synchronize()
+                outs.append(d_o.cpu().numpy())
+            _assert_same(outs[0], outs[1], "graph replay vs plain launches (count %d, batching %s)" % (count, batching))
+            return outs[0]
+
+        first = both(B)
+        both(B)            # new output buffer: the graph is rebuilt
+        both(5)            # other count
+        both(B, (3, 2))    # other batching
+        for plan in (p, q):
+            plan.set_psf_motion(21, 75.0, 0.02)
+        other = both(B, (3, 2))   # same arguments apart from the buffer; new filter contents
+        assert np.count_nonzero(other[0] != first[0]) > 0
+        ref = oracle.serial_channel(host[8], oracle.motion_blur_kernel(21, 75.0), 0.02)
+        assert float(np.max(np.abs(other[8] - ref))) <= 1e-4
+
+
 @pytest.mark.parametrize("pinned", [False, True])
 @pytest.mark.parametrize("mode_name", ["MODE_PARITY", "MODE_FAST"])
 def test_host_batch_pipeline_equals_one_by_one(fdr, oracle, mode_name, pinned):

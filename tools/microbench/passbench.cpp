@@ -1,7 +1,7 @@
 // passbench -- torch-free timing of the restoration passes through the C ABI of a libfdr build chosen at run time
 // (dlopen), so that one GPU call can compare several builds and sizes without paying a Python / torch start-up each.
 //
-//   passbench <libfdr.so> <size> [batch=8] [steps=10] [streams=1] [group=1] [mode=1] [flags=0] [two_sweep=-1 (library default)]
+//   passbench <libfdr.so> <size> [batch=8] [steps=10] [streams=1] [group=1] [mode=1] [flags=0] [two_sweep=-1 (library default)] [graph=0]
 //
 // Prints: per-pass mean device time (hipEvent pairs, one stream, un-overlapped) with the fraction of the 8 TB/s HBM
 // peak its algorithmic bytes give, then the batched throughput with the requested streams / group (median of 5).
@@ -58,6 +58,7 @@ int main(int argc, char** argv) {
     const int mode = argc > 7 ? std::atoi(argv[7]) : 1;
     const unsigned flags = argc > 8 ? (unsigned)std::strtoul(argv[8], nullptr, 0) : 0u;
     const int two_sweep = argc > 9 ? std::atoi(argv[9]) : -1;
+    const int graph = argc > 10 ? std::atoi(argv[10]) : 0;
     void* h = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
     if (!h) { std::printf("dlopen %s: %s\n", libpath, dlerror()); return 1; }
     Api api;
@@ -110,6 +111,7 @@ int main(int argc, char** argv) {
 
     // throughput with the requested streams x group
     FCK(api.set_batching(plan, streams, group));
+    if (graph) FCK(api.set_option(plan, 3 /* FDR_OPT_BATCH_GRAPH */, 1));
     for (int k = 0; k < 2; ++k) FCK(api.batch_dev(plan, d_in, P, B, S, S, S, d_out, P, S, 1, st));
     CK(hipStreamSynchronize(st));
     std::vector<double> t;
@@ -121,7 +123,7 @@ int main(int argc, char** argv) {
     }
     std::sort(t.begin(), t.end());
     const double per_img_us = t[2] / ((double)steps * B) * 1e6;
-    std::printf("  batched %d streams x %d per launch: %.2f us/image = %.0f Mpixels/s (median of 5; min %.2f max %.2f us)\n", streams, group, per_img_us,
+    std::printf("  batched%s %d streams x %d per launch: %.2f us/image = %.0f Mpixels/s (median of 5; min %.2f max %.2f us)\n", graph ? " (graph replay)" : "", streams, group, per_img_us,
                 P / per_img_us, t[0] / ((double)steps * B) * 1e6, t[4] / ((double)steps * B) * 1e6);
     // checksum so that variants can be compared for equality of results
     std::vector<float> host(P);
