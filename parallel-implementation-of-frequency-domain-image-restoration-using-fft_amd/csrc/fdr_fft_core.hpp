@@ -21,6 +21,23 @@
 
 namespace fdr {
 
+// Race fuzzer (timing-only debug builds, -DFDR_DEBUG_JITTER): every wave sleeps a pseudo-random 0..7 microseconds at the
+// points where it is about to write or read shared LDS state, so that the waves of a workgroup drift apart by more than
+// any phase lasts.  A missing barrier then corrupts data in (nearly) every workgroup instead of once in a thousand runs
+// under a second stream's load (round 2: pass A's separation buffer).  The GPU test suite is run against such a build
+// with tools/gpu_jitter.sh; product builds compile this to nothing.
+#ifdef FDR_DEBUG_JITTER
+__device__ __forceinline__ void fdr_jitter(unsigned salt) {
+    unsigned h = (threadIdx.x >> 6) * 0x9E3779B1u + salt * 0x85EBCA77u + (blockIdx.x + 131u * blockIdx.y) * 0xC2B2AE3Du;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    const unsigned n = __builtin_amdgcn_readfirstlane(h & 7u);
+    for (unsigned i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);  // 32 x 64 clocks, about 1 us
+}
+#define FDR_JITTER(salt) fdr_jitter((unsigned)(salt))
+#else
+#define FDR_JITTER(salt) ((void)0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // compile-time step plan for L = 2^LOGL: small radix first (so only radix-8 steps ever read a
 // padded layout), T = L/8 threads per transform.
@@ -470,11 +487,13 @@ struct FftCore {
             const int slot = SEQ0 + J * B + b;
             float2* buf = lds + (slot % NBUF) * St::BUF;
             if (NBUF == 1 && slot != 0) __syncthreads();  // everyone finished reading the previous slot
+            FDR_JITTER(2 * slot);
 #pragma unroll
             for (int u = 0; u < NU; ++u)
 #pragma unroll
                 for (int q = 0; q < RHO; ++q) buf[wbase[u] + q * WS] = v[b][u * RHO + q];
             __syncthreads();
+            FDR_JITTER(2 * slot + 1);
 #pragma unroll
             for (int u = 0; u < NUn; ++u)
 #pragma unroll
@@ -561,6 +580,7 @@ __device__ __forceinline__ void block_minmax_store(float mn, float mx, float2* _
         mx = fmaxf(mx, __shfl_xor(mx, off));
     }
     const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    FDR_JITTER(1001);
     if ((threadIdx.x & 63) == 0) red[wave] = make_float2(mn, mx);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -612,8 +632,10 @@ __device__ __forceinline__ void block_fold_partials(const float2* __restrict__ p
         mx = fmaxf(mx, __shfl_xor(mx, off));
     }
     const int nw = (blockDim.x + 63) >> 6;
+    FDR_JITTER(1003);
     if ((threadIdx.x & 63) == 0) fold_red[threadIdx.x >> 6] = make_float2(mn, mx);
     __syncthreads();
+    FDR_JITTER(1004);
     mn = fold_red[0].x; mx = fold_red[0].y;
     for (int w = 1; w < nw; ++w) {
         mn = fminf(mn, fold_red[w].x);

@@ -149,13 +149,17 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             float2* buf = grp_lds + ((SEQ1 + b) & 1) * St::BUF;
+#ifndef FDR_DEBUG_OMIT_SEPARATION_BARRIER  // (the race fuzzer's own check: with the barrier left out it must find the race)
             if (b == 1) __syncthreads();
+#endif
+            FDR_JITTER(2001 + b);
 #pragma unroll
             for (int u = 0; u < Core::NUL; ++u)
 #pragma unroll
                 for (int q = 0; q < Core::RHOL; ++q) buf[Core::out_index(tid, u, q)] = z[b][u * Core::RHOL + q];
         }
         __syncthreads();
+        FDR_JITTER(2003);
         const int j = tid & 3;                                    // row inside the 4-row group
         const float2* buf = grp_lds + ((SEQ1 + (j >> 1)) & 1) * St::BUF;  // packed pair holding row j
         const bool odd = (j & 1) != 0;                            // row b of the pair (else row a)
@@ -325,12 +329,14 @@ __global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<
         for (int b = 0; b < 2; ++b) {
             float2* buf = lds + ((SEQ1 + b) & 1) * St::BUF;
             if (b == 1) __syncthreads();  // pair 1's buffer was read by the transform's last exchange (see fft_rows4_fwd_packed_kernel)
+            FDR_JITTER(2011 + b);
 #pragma unroll
             for (int u = 0; u < Core::NUL; ++u)
 #pragma unroll
                 for (int q = 0; q < Core::RHOL; ++q) buf[Core::out_index(tid, u, q)] = z[b][u * Core::RHOL + q];
         }
         __syncthreads();
+        FDR_JITTER(2013);
         float2* __restrict__ dst = dst_of(im);
         const int r0 = g * 4;
         // (opaque copy of the thread index: the LDS and panel addresses below are loop invariant, and hoisted out of
@@ -524,6 +530,7 @@ __device__ __forceinline__ void rows4_pack_mirror(int tid, const float2 (&y)[4][
     constexpr int L = St::L, HQ = Core::RHO0 / 2;
     float2* m0 = grp_lds;
     float2* m1 = grp_lds + St::BUF;
+    FDR_JITTER(3001);
 #pragma unroll
     for (int u = 0; u < Core::NU0; ++u)
 #pragma unroll
@@ -541,6 +548,7 @@ __device__ __forceinline__ void rows4_pack_mirror(int tid, const float2 (&y)[4][
             }
         }
     __syncthreads();
+    FDR_JITTER(3002);
 #pragma unroll
     for (int u = 0; u < Core::NU0; ++u)
 #pragma unroll
@@ -1283,6 +1291,7 @@ __device__ __forceinline__ void packed_column_filter(float2 (&cur)[4][8], const 
     float2* bufc = grp_lds + (SEQ & 1) * St::BUF;
     float2* bufs = grp_lds + ((SEQ + 1) & 1) * St::BUF;
     __syncthreads();  // the other buffer was read by the last exchange of the forward transform
+    FDR_JITTER(4001);
 #pragma unroll
     for (int u = 0; u < Core::NUL; ++u)
 #pragma unroll
@@ -1292,6 +1301,7 @@ __device__ __forceinline__ void packed_column_filter(float2 (&cur)[4][8], const 
             bufs[k] = flt[0][u * Core::RHOL + q];
         }
     __syncthreads();
+    FDR_JITTER(4002);
 #pragma unroll
     for (int u = 0; u < Core::NUL; ++u)
 #pragma unroll
@@ -1587,6 +1597,7 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
         float2* bufc = grp_lds + (SEQ & 1) * St::BUF;
         float2* bufs = grp_lds + ((SEQ + 1) & 1) * St::BUF;
         __syncthreads();
+        FDR_JITTER(4011);
         // (once per image, on one workgroup: kept cheap in REGISTERS, not in time -- the filter values go to LDS two at
         // a time behind compiler barriers and every slot is finished before the next one starts, so this path adds
         // nothing to the pressure of the common one)
@@ -1602,6 +1613,7 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
             asm volatile("" ::: "memory");
         }
         __syncthreads();
+        FDR_JITTER(4012);
         if (g == 0) {
 #pragma unroll
             for (int u = 0; u < Core::NUL; ++u)
