@@ -268,7 +268,10 @@ def main():
                     tj = json.load(open(tfile))
                     key = "%s/%s/%d" % (args.mode, spectrum, S)
                     if key in tj and base_name in tj[key]:
-                        roofline["traffic"] = tj[key][base_name] * nimg
+                        ent = tj[key][base_name]  # PMC bytes per launch of `images` images (tools/summarize_profiles.py)
+                        roofline["traffic"] = ent["per_launch"] * nimg / ent["images"] if isinstance(ent, dict) else ent * nimg
+                        if isinstance(ent, dict) and ent["images"] != nimg:
+                            roofline["traffic_note"] = "scaled from a %d-image launch" % ent["images"]
                 except Exception:
                     pass
         vals = sorted(images * P / 1e6 / t for t in reps)

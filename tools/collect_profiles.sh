@@ -4,7 +4,8 @@
 #   * rocprofv3 --kernel-trace --stats of bench.py --streams 1 at 4096^2 and 8192^2 (un-overlapped kernel durations;
 #     the launch grouping is bench's default, so the averages are per launch as bench's roofline reports them)
 #   * rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no trace options beside them) of
-#     bench.py --streams 1 --group 1 at both sizes, and on a known-size float4 copy (calibration of FETCH_SIZE on gfx950)
+#     bench.py --streams 1 at both sizes (bench's own launch grouping: the counters are per LAUNCH of 4 / 2 images), and on a
+#     known-size float4 copy (calibration of FETCH_SIZE on gfx950)
 #   * the 2-rank rehearsal of the N > 1 bench path on this one GPU (backend gloo, --one-device), weak and strong scaling
 #   usage: tools/collect_profiles.sh <tag>
 set -o pipefail
@@ -21,8 +22,8 @@ for S in 4096 8192; do
   if [ $S = 8192 ]; then B="--batch 12 --steps 6 --warmup 2"; else B="--batch 48 --steps 10 --warmup 3"; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$S -o kt -- python3 bench.py --size $S $B --streams 1 --repeats 1 --no-cpu-baseline --no-psf-recompute > $OUT/kt_$S.log 2>&1; echo "kt_$S rc=$?" >> $OUT/status.txt
   grep '^{' $OUT/kt_$S.log | tail -n 1 > $OUT/bench_line_streams1_$S.json
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$S -o fetch -- python3 bench.py --size $S --steps 2 --warmup 1 --batch 4 --streams 1 --group 1 --repeats 1 --no-cpu-baseline --no-psf-recompute > $OUT/fetch_$S.log 2>&1; echo "fetch_$S rc=$?" >> $OUT/status.txt
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$S -o write -- python3 bench.py --size $S --steps 2 --warmup 1 --batch 4 --streams 1 --group 1 --repeats 1 --no-cpu-baseline --no-psf-recompute > $OUT/write_$S.log 2>&1; echo "write_$S rc=$?" >> $OUT/status.txt
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$S -o fetch -- python3 bench.py --size $S --steps 2 --warmup 1 --batch 8 --streams 1 --repeats 1 --no-cpu-baseline --no-psf-recompute > $OUT/fetch_$S.log 2>&1; echo "fetch_$S rc=$?" >> $OUT/status.txt
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$S -o write -- python3 bench.py --size $S --steps 2 --warmup 1 --batch 8 --streams 1 --repeats 1 --no-cpu-baseline --no-psf-recompute > $OUT/write_$S.log 2>&1; echo "write_$S rc=$?" >> $OUT/status.txt
 done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -o cal -- ./tools/microbench/membench > $OUT/cal_fetch.log 2>&1; echo "cal_fetch rc=$?" >> $OUT/status.txt
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -o cal -- ./tools/microbench/membench > $OUT/cal_write.log 2>&1; echo "cal_write rc=$?" >> $OUT/status.txt

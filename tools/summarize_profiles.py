@@ -68,6 +68,7 @@ def main():
             continue
         fe, wr = counter(fe_f[0], "FETCH_SIZE"), counter(wr_f[0], "WRITE_SIZE")
         traffic, rows = {}, []
+        images = 4 if size <= 4096 else 2  # images per launch of bench.py's default grouping (what the PMC runs used)
         for kname, vals in fe.items():
             for key, pname in PASS_OF.items():
                 if key.startswith("fft_rows4_inv_"):  # last template argument: 0 raw plane (C'), 1 min/max only (C1), 2 normalised (C2)
@@ -77,11 +78,12 @@ def main():
                     rd = statistics.median(vals) * round(fetch_factor) * 1024.0
                     wv = [v for k, v in wr.items() if k == kname]
                     wt = statistics.median(wv[0]) * 1024.0 if wv else 0.0
-                    traffic[pname] = rd + wt
+                    traffic[pname] = {"per_launch": rd + wt, "images": images}
                     rows.append((pname, kname[:90], len(vals), statistics.median(vals), statistics.median(wv[0]) if wv else 0, rd, wt))
         with open(os.path.join(dst, "%s_hbm_traffic_%d.csv" % (tag, size)), "w", newline="") as f:
             w = csv.writer(f)
             w.writerow(["calibration", "copy_f4 128 MiB", "FETCH_SIZE_KiB", cf, "factor", fetch_factor, "WRITE_SIZE_KiB", cw, "factor", write_factor])
+            w.writerow(["(per LAUNCH of %d images)" % images])
             w.writerow(["pass", "kernel", "dispatches", "FETCH_SIZE_median_KiB", "WRITE_SIZE_median_KiB", "read_bytes(corrected)", "write_bytes"])
             for r in rows:
                 w.writerow(r)
