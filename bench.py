@@ -41,7 +41,6 @@ PASS_BYTES = {
     },
     "half": {
         "A rows: pad+FFT (real->complex)": 8, "B' cols: FFT*W*IFFT": 12, "C' rows: IFFT+real+minmax": 8, "E normalize+crop": 8,
-        "C'E rows: IFFT+minmax+normalize+crop (fused)": 8, "E' fixup (no-op unless a wait timed out)": 0,
         # two-sweep normalisation (default): the inverse row pass runs twice, no raw real plane
         "C1 rows: IFFT+minmax": 4, "C2 rows: IFFT+normalize+crop": 8,
     },
@@ -147,8 +146,6 @@ def main():
         B, first_image, scaling = args.batch, rank * args.batch, "weak"
 
     flags = fdr.FLAG_FULL_SPECTRUM if os.environ.get("FDR_FULL_SPECTRUM") == "1" else 0
-    if os.environ.get("FDR_FUSED_NORM") == "1":
-        flags |= fdr.FLAG_FUSED_NORM
     spectrum = "half" if (args.mode == "fast" and not (flags & fdr.FLAG_FULL_SPECTRUM) and S >= 32) else "full"
     plan = fdr.Plan(S, S, mode, device=local_rank, flags=flags)
     if args.raw_plane:

@@ -47,14 +47,6 @@ extern "C" {
 #define FDR_FLAG_FULL_SPECTRUM 32u /* fast mode: keep all N columns of the (Hermitian) spectrum instead of the
                                       non-redundant half (the complex-to-complex byte count of SURVEY.md 8d)     */
 
-#define FDR_FLAG_FUSED_NORM 128u /* fast mode: pass C' (rows inverse + min/max) and pass E (normalise + crop) as ONE launch
-                                    that keeps the raw plane in registers across a grid-wide min/max hand-off (-8 bytes
-                                    per pixel; images of at most 4 row groups per CU, i.e. up to 4096 x 4096 on 256 CUs).
-                                    Opt-in: a fused launch occupies every CU while it waits, so it does not overlap with
-                                    other images' passes in the batched multi-stream mode, where the two-launch form is
-                                    faster (measured: DESIGN.md section 5).  The wait is bounded (FDR_OPT_FUSED_SPIN_LIMIT);
-                                    a workgroup whose wait runs out writes raw rows that a fix-up launch normalises.      */
-
 #define FDR_FLAG_TABLES_ONLY 1024u /* twiddle tables and min/max scratch only, no M x N workspaces: a plan for the slab
                                       primitives (fdr_slab_*) of the single-image multi-GPU mode, where every rank
                                       holds only its rows of the image; fdr_wiener_* / fdr_fft2d_* / fdr_set_psf*
@@ -93,8 +85,6 @@ int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan
 int fdr_plan_destroy(fdr_plan* plan);
 int fdr_plan_dims(const fdr_plan* plan, int* M, int* N, int* mode);
 /* tunables of a plan */
-#define FDR_OPT_FUSED_SPIN_LIMIT 1 /* FDR_FLAG_FUSED_NORM: sweeps (about 0.5 us each) a workgroup waits for the other
-                                      workgroups' min/max before it falls back to the two-launch form; default 20000 */
 #define FDR_OPT_TWO_SWEEP_NORM 2   /* fast mode, half spectrum: 1 = the inverse row pass runs twice (min/max only, then
                                       again with the normalisation applied on store) instead of writing a raw real plane
                                       that a normalise pass reads back: 12 instead of 16 bytes per pixel for the last two

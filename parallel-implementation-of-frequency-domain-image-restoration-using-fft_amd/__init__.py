@@ -22,13 +22,11 @@ MODE_PARITY = 0
 MODE_FAST = 1
 FLAG_SIMPLE_PATH = 1
 FLAG_FULL_SPECTRUM = 32
-FLAG_FUSED_NORM = 128
 FLAG_ANY_SIZE = 512
 FLAG_TABLES_ONLY = 1024
 NORM_PADDED = 1
 NORM_CROPPED = 0
 MAX_PASSES = 16
-OPT_FUSED_SPIN_LIMIT = 1
 OPT_TWO_SWEEP_NORM = 2
 OPT_BATCH_GRAPH = 3
 PHASES = ("alloc", "h2d", "pre", "compute", "d2h", "post")  # the reference Profiler's buckets, fft/fft_gpu.cu:17-57

@@ -153,8 +153,6 @@ struct fdr_plan {
     struct Slot {
         float2* work = nullptr; float2* work2 = nullptr; float* raw = nullptr; float* mm = nullptr; float2* mm_part = nullptr;
         hipStream_t stream = nullptr; hipEvent_t done = nullptr;
-        // fused pass C'+E: 2 granules + 1 fallback word per workgroup, launch counter (the granule epoch)
-        unsigned long long* gran = nullptr; unsigned* fallback = nullptr; unsigned epoch = 0;
     };
     static constexpr int kMaxSlots = 8;
     Slot slots[kMaxSlots];
@@ -163,9 +161,6 @@ struct fdr_plan {
     int group = 1;    // images per pass-B' launch (panel path)
     hipEvent_t fork = nullptr;
     size_t ws_elems = 0;  // elements of one work / raw buffer
-    // fused pass C'+E (fast panel path, half spectrum, images of at most 4 row groups per CU)
-    bool fused_norm = false; int fused_R = 0, fused_nwg = 0;
-    unsigned spin_limit = 20000;     // sweeps (~0.5 us each) before a waiting workgroup falls back
     bool two_sweep = true;           // FDR_OPT_TWO_SWEEP_NORM: passes C1 + C2 instead of C' + E (fast half-spectrum path)
     // FDR_OPT_BATCH_GRAPH: the launches of one fdr_wiener_batch_f32_dev call (fork, every pass of every group on the
     // internal streams, join) captured once as a hipGraph and replayed while the call's arguments stay the same
@@ -182,8 +177,6 @@ struct fdr_plan {
     hipGraphExec_t graph_exec = nullptr;
     GraphKey graph_key{};
     hipStream_t cap_stream = nullptr;
-    hipEvent_t fused_done = nullptr; // fused launches of one plan never overlap: each holds every CU while it waits
-    bool fused_recorded = false;
 };
 
 namespace {
@@ -246,8 +239,6 @@ const char* const kPassRowsMinmaxN[5] = {nullptr, nullptr, "C1 rows: IFFT+minmax
 const char* const kPassRowsNorm = "C2 rows: IFFT+normalize+crop";
 const char* const kPassRowsNormN[5] = {nullptr, nullptr, "C2 rows: IFFT+normalize+crop [2 images]", "C2 rows: IFFT+normalize+crop [3 images]",
                                        "C2 rows: IFFT+normalize+crop [4 images]"};
-const char* const kPassRowsInvNorm = "C'E rows: IFFT+minmax+normalize+crop (fused)";
-const char* const kPassFixup = "E' fixup (no-op unless a wait timed out)";
 const char* const kPassSimple = "simple path (reference-shaped)";
 
 int upload(float2** dst, const std::vector<float2>& v) {
@@ -333,27 +324,7 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
     return FDR_OK;
 }
 
-#ifdef FDR_DEBUG_STAMPS
-unsigned long long* g_debug_stamps = nullptr;
-unsigned long long* debug_stamps() {  // timing-only builds: one pinned buffer per process, dumped by fdr_debug_dump_stamps
-    if (!g_debug_stamps) {
-        (void)hipHostMalloc((void**)&g_debug_stamps, 2048 * 32 * sizeof(unsigned long long));
-        memset(g_debug_stamps, 0, 2048 * 32 * 8);
-    }
-    return g_debug_stamps;
-}
-#endif
 
-int ensure_fused_sync(fdr_plan* p, fdr_plan::Slot& w) {
-    if (w.gran) return FDR_OK;
-    const size_t n = (size_t)p->fused_nwg;
-    FDR_HIP(hipMalloc((void**)&w.gran, 2 * n * sizeof(unsigned long long)));
-    FDR_HIP(hipMalloc((void**)&w.fallback, n * sizeof(unsigned)));
-    FDR_HIP(hipMemset(w.gran, 0, 2 * n * sizeof(unsigned long long)));  // epoch 0 never matches a launch
-    FDR_HIP(hipMemset(w.fallback, 0, n * sizeof(unsigned)));
-    w.epoch = 0;
-    return FDR_OK;
-}
 
 // ---- fast panel path in three stages, so that pass B' can be launched once for a group of images ----
 int panel_stage_A(fdr_plan* p, fdr_plan::Slot& w, const float* d_img, int rows, int cols, int stride, hipStream_t s) {
@@ -370,43 +341,12 @@ int panel_stage_B(fdr_plan* p, fdr_plan::Slot* const* ws, int n, hipStream_t s) 
     c.data = ws[0]->work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.num_cu = p->num_cu;
     c.pstride = p->pstride; c.npanels = p->npanels; c.packed0 = p->half ? 1 : 0;
     c.batch.nimg = n;
-#ifdef FDR_DEBUG_STAMPS
-    if (getenv("FDR_STAMP_COLS")) c.batch.stamps = debug_stamps();
-#endif
     for (int k = 0; k < n; ++k) c.batch.data[k] = ws[k]->work;
     FDR_HIP(launch_cols_panel(p->logM, COL_FUSED, c, p->tw_col_f, s));
     return FDR_OK;
 }
 int panel_stage_CE(fdr_plan* p, fdr_plan::Slot& w, int rows, int cols, float* d_out, int out_stride, int mm_rows,
                    int mm_cols, hipStream_t s) {
-    if (p->fused_norm) {  // C'+E in one launch: the raw plane stays in registers across a granule hand-off
-        int rc = ensure_fused_sync(p, w);
-        if (rc != FDR_OK) return rc;
-        RowArgs a{};
-        a.src_c = w.work; a.dst_real = w.raw; a.mm_part = w.mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
-        a.pstride = p->pstride; a.half = 1;
-        NormArgs na{};
-        if (++w.epoch == 0) w.epoch = 1;
-        na.gran = w.gran; na.fallback = w.fallback; na.epoch = w.epoch; na.spin_limit = p->spin_limit;
-        na.out = d_out; na.rows = rows; na.cols = cols; na.out_stride = out_stride;
-#ifdef FDR_DEBUG_STAMPS
-        na.stamps = debug_stamps();
-#endif
-        {
-            ScopedPass t(p, s, kPassRowsInvNorm);
-            // every workgroup of a fused launch holds its CU until all of them have published: two such launches must
-            // not share the chip (streams of the batched mode), so each waits for the previous one of this plan
-            if (p->fused_recorded) FDR_HIP(hipStreamWaitEvent(s, p->fused_done, 0));
-            FDR_HIP(launch_rows4_inv_norm(p->logN, p->fused_R, p->fused_nwg, a, na, p->tw_row_f, s));
-            FDR_HIP(hipEventRecord(p->fused_done, s));
-            p->fused_recorded = true;
-        }
-        {
-            ScopedPass t(p, s, kPassFixup);
-            FDR_HIP(launch_normalize_fixup(p->logN, p->fused_R, p->fused_nwg, a, na, s));
-        }
-        return FDR_OK;
-    }
     if (p->two_sweep && p->half) {
         // C1 + C2: the inverse row transform runs twice -- once for the min/max alone, once more with the normalisation
         // applied on store -- so the raw real plane never exists: 4 + 8 bytes per pixel instead of 8 + 8
@@ -443,7 +383,7 @@ int panel_stage_CE(fdr_plan* p, fdr_plan::Slot& w, int rows, int cols, float* d_
 }
 
 // the same passes for a GROUP of 2..4 images in one launch each (blockIdx.y = image); packed half-spectrum path only
-bool can_batch_rows(const fdr_plan* p) { return p->half && !p->fused_norm; }
+bool can_batch_rows(const fdr_plan* p) { return p->half; }
 int panel_stage_A_batch(fdr_plan* p, fdr_plan::Slot* const* ws, int n, const float* const* d_imgs, int rows, int cols, int stride,
                         hipStream_t s) {
     ScopedPass t(p, s, kPassRowsFwdN[n]);
@@ -635,8 +575,6 @@ static int plan_create_impl(fdr_plan* p, int device, int M, int N, int mode, uns
         p->half = N >= 32 && (flags & FDR_FLAG_FULL_SPECTRUM) == 0;
         p->npanels = p->half ? N / 8 : N / 4;
         P = (size_t)p->npanels * p->pstride;
-        p->fused_norm = p->half && (flags & FDR_FLAG_FUSED_NORM) != 0 &&
-                        rows4_fused_geometry(p->logN, M, p->num_cu, &p->fused_R, &p->fused_nwg) != 0;
     }
     std::vector<float2> t;
     int rc = FDR_OK;
@@ -662,8 +600,6 @@ static int plan_create_impl(fdr_plan* p, int device, int M, int N, int mode, uns
         hipMalloc((void**)&p->mm_part, (size_t)(p->mm_part_cap = (int)(((size_t)N + 255) / 256 * M + 8192)) * sizeof(float2)) != hipSuccess ||
         (p->simple && !p->tables_only && hipMalloc((void**)&p->work2, P * sizeof(float2)) != hipSuccess))
         return fail(FDR_ERR_ALLOC, "fdr_plan_create: hipMalloc of the plan workspace failed");
-    if (p->fused_norm && hipEventCreateWithFlags(&p->fused_done, hipEventDisableTiming) != hipSuccess)
-        return fail(FDR_ERR_HIP, "fdr_plan_create: hipEventCreate failed");
     p->ws_elems = P;
     p->slots[0].work = p->work; p->slots[0].work2 = p->work2; p->slots[0].raw = p->raw; p->slots[0].mm = p->mm;
     p->slots[0].mm_part = p->mm_part;
@@ -708,12 +644,10 @@ int fdr_plan_destroy(fdr_plan* p) {
     for (int k = 0; k < fdr_plan::kMaxSlots; ++k) {
         if (p->slots[k].stream) (void)hipStreamDestroy(p->slots[k].stream);
         if (p->slots[k].done) (void)hipEventDestroy(p->slots[k].done);
-        (void)hipFree(p->slots[k].gran); (void)hipFree(p->slots[k].fallback);
     }
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     if (p->fork) (void)hipEventDestroy(p->fork);
-    if (p->fused_done) (void)hipEventDestroy(p->fused_done);
     (void)hipFree(p->tw_row_f); (void)hipFree(p->tw_row_i); (void)hipFree(p->tw_col_f); (void)hipFree(p->tw_col_i);
     if (p->naive_col != p->naive_row) (void)hipFree(p->naive_col);
     (void)hipFree(p->naive_row);
@@ -745,10 +679,6 @@ int fdr_plan_set_option(fdr_plan* p, int option, long long value) {
         case FDR_OPT_TWO_SWEEP_NORM:
             if (value != 0 && value != 1) return fail(FDR_ERR_ARG, "fdr_plan_set_option: FDR_OPT_TWO_SWEEP_NORM takes 0 or 1");
             p->two_sweep = value != 0;
-            return FDR_OK;
-        case FDR_OPT_FUSED_SPIN_LIMIT:
-            if (value < 0 || value > 0xffffffffLL) return fail(FDR_ERR_ARG, "fdr_plan_set_option: spin limit out of range");
-            p->spin_limit = (unsigned)value;
             return FDR_OK;
         default:
             return fail(FDR_ERR_ARG, "fdr_plan_set_option: unknown option");
@@ -842,8 +772,8 @@ int fdr_wiener_batch_f32_dev(fdr_plan* p, const float* d_imgs, size_t img_pitch,
     int rc = check_image_args(p, d_imgs, rows, cols, stride, d_out, out_stride);
     if (rc != FDR_OK) return rc;
     // graph replay: launch-bound batches (small images) pay one graph launch instead of 4 kernel launches per group.
-    // Not with per-kernel profiling (host-side event pairs) nor with the fused C'E pass (allocates on first use).
-    if (p->batch_graph && p->panel && !p->timer.enabled && !p->fused_norm) {
+    // Not with per-kernel profiling (host-side event pairs).
+    if (p->batch_graph && p->panel && !p->timer.enabled) {
         const fdr_plan::GraphKey key{d_imgs, d_out, img_pitch, out_pitch, count, rows, cols, stride, out_stride, norm_area, p->nstreams, p->group,
                                      p->two_sweep, p->K};
         if (!(p->graph_exec && key == p->graph_key)) {
@@ -1470,15 +1400,6 @@ extern "C" int fdr_batch_run(const fdr_batch_desc* d, fdr_batch_stats* st) {
     return FDR_OK;
 }
 
-#ifdef FDR_DEBUG_STAMPS
-// timing-only builds, not part of fdr.h: copies the last fused launch's per-workgroup stamps (32 words each)
-int fdr_debug_dump_stamps(unsigned long long* dst, int nwg) {
-    if (!g_debug_stamps) return FDR_ERR_STATE;
-    (void)hipDeviceSynchronize();
-    memcpy(dst, g_debug_stamps, (size_t)nwg * 32 * sizeof(unsigned long long));
-    return FDR_OK;
-}
-#endif
 
 int fdr_plan_profile(fdr_plan* p, int enable) {
     if (!p) return fail(FDR_ERR_ARG, "fdr_plan_profile: null plan");

@@ -58,27 +58,10 @@ struct RowArgs {
     RowBatch batch;     // rows4 packed kernels: several images per launch
 };
 
-// Fused pass C'+E (rows inverse + min/max + normalise + crop in ONE launch, fast panel path, images whose real plane
-// fits the register files of the chip): every workgroup keeps its rows in registers, publishes its (min, max) as two
-// 8-byte {epoch, value} granules, waits until all workgroups' granules carry this launch's epoch, then normalises
-// from registers -- the raw plane never goes to HBM (-8 bytes per pixel).  A workgroup whose (bounded) wait times out
-// writes its raw rows instead and raises its fallback word; normalize_fixup_kernel, launched right behind, repairs
-// exactly those rows, so the result is always complete.
-struct NormArgs {
-    unsigned long long* gran;  // 2 granules per workgroup, written with agent-scope atomic stores
-    unsigned* fallback;        // 1 word per workgroup
-    unsigned epoch;            // > 0, strictly increasing per `gran` buffer
-    unsigned spin_limit;       // sweeps before a waiting workgroup gives up
-    float* out;                // rows x cols result, row stride out_stride
-    int rows, cols, out_stride;
-    unsigned long long* stamps;  // timing-only builds (FDR_DEBUG_STAMPS): 32 words per workgroup, else unused
-};
-
 // up to 4 images' spectra handled by ONE persistent pass-B' launch (their panels form one tile sequence)
 struct PanelBatch {
     float2* data[4];
     int nimg;  // 0 or 1: use ColArgs::data only
-    unsigned long long* stamps;  // timing-only builds (FDR_DEBUG_STAMPS), else unused
 };
 
 struct ColArgs {
@@ -108,10 +91,6 @@ hipError_t launch_cols(int logm, int mode, ColKind kind, const ColArgs& a, const
 hipError_t launch_rows4(int logl, RowIn in, RowOut out, const RowArgs& a, const float2* tw_fwd, hipStream_t s);
 // min/max partials pass C' writes per image when `nimg` images share a launch on a device with num_cu CUs
 int rows4_minmax_partials(int logl, int M, int num_cu, int nimg);
-// fused C'+E: geometry (returns 0 when this shape cannot run fused: R row groups per thread group, nwg workgroups)
-int rows4_fused_geometry(int logl, int M, int num_cu, int* R, int* nwg);
-hipError_t launch_rows4_inv_norm(int logl, int R, int nwg, const RowArgs& a, const NormArgs& na, const float2* tw_fwd, hipStream_t s);
-hipError_t launch_normalize_fixup(int logl, int R, int nwg, const RowArgs& a, const NormArgs& na, hipStream_t s);
 // cols_panel: COL_FWD (in place) or COL_FUSED (FFT . W . IFFT, persistent + register double-buffered)
 hipError_t launch_cols_panel(int logm, ColKind kind, const ColArgs& a, const float2* tw_fwd, hipStream_t s);
 

@@ -805,247 +805,6 @@ static int rows4_inv_pers_grid(int M, int num_cu, int nimg) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Fused pass C'+E (see NormArgs in fdr_kernels.hpp).  Thread group g of workgroup w owns the 4-row groups
-//   gi(r) = (r * nwg + w) * G + g,  r = 0 .. R-1
-// (round-robin over workgroups, so at any time the chip reads one contiguous band of rows).  The R results stay
-// in registers (32 floats per group and thread); the raw spectrum of group r+1 is requested before group r is
-// transformed and lands behind it.  Straight-line code (R is a template parameter): no loop-carried registers.
-// ---------------------------------------------------------------------------------------------
-#ifdef FDR_DEBUG_STAMPS  // timing-only builds: per-workgroup timeline of the fused kernel (100 MHz clock), own buffer
-#define FDR_STAMP(args, w, k) do { if (threadIdx.x == 0 && (args).stamps) (args).stamps[(size_t)(w) * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define FDR_STAMP(args, w, k) do { } while (0)
-#endif
-
-// round r of fft_rows4_inv_norm_kernel (compile-time recursion: the LDS slot sequence of the core is a template argument)
-template <int LOGL, int R, int r>
-__device__ __forceinline__ void fused_round(const RowArgs& a, const float2* __restrict__ tw_fwd,
-                                            const typename FftCore<LOGL, 2, 2, PolicyFast>::Bases& bases, float2* grp_lds, int tid,
-                                            int g, int w, int nwg, float2 (&y)[4][8], float2 (&zk)[R][2][8], float& mn, float& mx,
-                                            const NormArgs& na) {
-    using Core = FftCore<LOGL, 2, 2, PolicyFast>;
-    constexpr int G = Rows4PackGeom<LOGL>::G;
-    const int M = a.M;
-    const int r0 = ((r * nwg + w) * G + g) * 4;
-    rows4_pack<LOGL, true, Core>(tid, y, zk[r]);
-    FDR_STAMP(na, w, 8 + 4 * r);
-    if constexpr (r + 1 < R) {
-        const int r1 = (((r + 1) * nwg + w) * G + g) * 4;
-        rows4_load_raw<LOGL, true, Core>(a, r1 < M ? r1 : 0, tid, y);  // inactive groups read rows 0..3, count and store nothing
-    }
-    FDR_STAMP(na, w, 9 + 4 * r);
-    Core::template run<r * Core::SLOTS, true>(zk[r], grp_lds, tw_fwd, bases, tid);
-    FDR_STAMP(na, w, 10 + 4 * r);
-    if (r0 < M) {
-        if (r0 + 3 < a.mm_rows && a.mm_cols >= Steps<LOGL>::L) {  // whole group counted (always, with NORM_PADDED)
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                mn = fminf(fminf(mn, zk[r][0][s].x), fminf(zk[r][0][s].y, fminf(zk[r][1][s].x, zk[r][1][s].y)));
-                mx = fmaxf(fmaxf(mx, zk[r][0][s].x), fmaxf(zk[r][0][s].y, fmaxf(zk[r][1][s].x, zk[r][1][s].y)));
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < Core::NUL; ++u)
-#pragma unroll
-                for (int q = 0; q < Core::RHOL; ++q) {
-                    const int s = u * Core::RHOL + q;
-                    const int n = Core::out_index(tid, u, q);
-                    const float v4[4] = {zk[r][0][s].x, zk[r][0][s].y, zk[r][1][s].x, zk[r][1][s].y};
-#pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        if (r0 + b < a.mm_rows && n < a.mm_cols) {
-                            mn = fminf(mn, v4[b]);
-                            mx = fmaxf(mx, v4[b]);
-                        }
-                }
-        }
-    }
-    FDR_STAMP(na, w, 11 + 4 * r);
-    if constexpr (r + 1 < R) fused_round<LOGL, R, r + 1>(a, tw_fwd, bases, grp_lds, tid, g, w, nwg, y, zk, mn, mx, na);
-}
-
-template <int LOGL, int R>
-__global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_norm_kernel(const RowArgs a, const NormArgs na,
-                                                                                        const float2* __restrict__ tw_fwd) {
-    using St = Steps<LOGL>;
-    using Geo = Rows4PackGeom<LOGL>;
-    constexpr int G = Geo::G, T = St::T, L = St::L;
-    using Core = FftCore<LOGL, 2, 2, PolicyFast>;
-    __shared__ float2 lds[G * 2 * St::BUF];
-    __shared__ float2 red[16];
-    __shared__ float res[4];
-    const int g = G == 1 ? 0 : (int)(threadIdx.x >> St::LOGT);
-    const int tid = threadIdx.x & (T - 1);
-    const int M = a.M;
-    const int nwg = gridDim.x, w = blockIdx.x;
-
-    typename Core::Bases bases;
-    Core::init_bases(bases, tw_fwd, tid);
-
-    float2 zk[R][2][8];  // results: zk[r][0][s] = (row 0, row 1), zk[r][1][s] = (row 2, row 3) of group r at column out_index(s)
-    float mn = __builtin_inff(), mx = -__builtin_inff();
-    float2 y[4][8];
-    {
-        const int r0 = (w * G + g) * 4;
-        rows4_load_raw<LOGL, true, Core>(a, r0 < M ? r0 : 0, tid, y);
-    }
-    FDR_STAMP(na, w, 0);
-    fused_round<LOGL, R, 0>(a, tw_fwd, bases, lds + g * 2 * St::BUF, tid, g, w, nwg, y, zk, mn, mx, na);
-    FDR_STAMP(na, w, 1);
-
-    // workgroup min / max -> thread 0
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        mn = fminf(mn, __shfl_xor(mn, off));
-        mx = fmaxf(mx, __shfl_xor(mx, off));
-    }
-    const int wave = threadIdx.x >> 6, nwaves = (Geo::THREADS + 63) >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) red[wave] = make_float2(mn, mx);
-    __syncthreads();
-    if (wave == 0) {
-        if (lane == 0) {
-            for (int k = 1; k < nwaves; ++k) {
-                mn = fminf(mn, red[k].x);
-                mx = fmaxf(mx, red[k].y);
-            }
-            // publish: the value IS the flag -- one 8-byte {epoch, bits} granule each, agent-scope (write-through) stores
-            __hip_atomic_store(na.gran + 2 * w, ((unsigned long long)na.epoch << 32) | __float_as_uint(mn), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(na.gran + 2 * w + 1, ((unsigned long long)na.epoch << 32) | __float_as_uint(mx), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            res[2] = mn; res[3] = mx;  // own partial, for the fallback path
-        }
-        FDR_STAMP(na, w, 2);
-        // sweep all 2 * nwg granules until every tag carries this launch's epoch (bounded)
-        float gmn, gmx;
-        bool timed_out = false;
-        for (unsigned spins = 0;; ++spins) {
-            bool ok = true;
-            gmn = __builtin_inff(); gmx = -__builtin_inff();
-            for (int i = lane; i < 2 * nwg; i += 64) {
-                const unsigned long long x = __hip_atomic_load(na.gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = ok && (unsigned)(x >> 32) == na.epoch;
-                const float v = __uint_as_float((unsigned)x);
-                if (i & 1) gmx = fmaxf(gmx, v); else gmn = fminf(gmn, v);
-            }
-            if (__all(ok)) break;
-            if (spins >= na.spin_limit) { timed_out = true; break; }  // uniform over the wave
-            __builtin_amdgcn_s_sleep(16);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            gmn = fminf(gmn, __shfl_xor(gmn, off));
-            gmx = fmaxf(gmx, __shfl_xor(gmx, off));
-        }
-        if (lane == 0) { res[0] = timed_out ? 1.0f : 0.0f; if (!timed_out) { res[2] = gmn; res[3] = gmx; } }
-    }
-    __syncthreads();
-    FDR_STAMP(na, w, 3);
-    const bool fallback = res[0] != 0.0f;
-    float fscale = 1.0f, fshift = 0.0f;
-    if (!fallback) minmax_to_scale_shift(res[2], res[3], fscale, fshift);
-    else if (threadIdx.x == 0) {
-        a.mm_part[w] = make_float2(res[2], res[3]);
-        na.fallback[w] = 1u;
-    }
-
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int r0 = ((r * nwg + w) * G + g) * 4;
-        if (r0 >= M) continue;
-        if (!fallback && r0 + 3 < na.rows && na.cols >= L) {
-            // common case, no crop inside this group: four row bases (uniform when G == 1) + the lane's column
-            float* o0 = na.out + (size_t)r0 * na.out_stride + tid;
-            float* o1 = o0 + na.out_stride;
-            float* o2 = o1 + na.out_stride;
-            float* o3 = o2 + na.out_stride;
-#pragma unroll
-            for (int u = 0; u < Core::NUL; ++u)
-#pragma unroll
-                for (int q = 0; q < Core::RHOL; ++q) {
-                    const int s = u * Core::RHOL + q;
-                    const int c = u * T + (q << Core::LOGOUT);
-#ifdef FDR_DEBUG_SKIP_MEM
-                    if (zk[r][0][s].x != 1.2345e-30f) continue;
-#endif
-                    const float p0 = zk[r][0][s].x * fscale, p1 = zk[r][0][s].y * fscale;
-                    const float p2 = zk[r][1][s].x * fscale, p3 = zk[r][1][s].y * fscale;
-                    o0[c] = p0 + fshift; o1[c] = p1 + fshift; o2[c] = p2 + fshift; o3[c] = p3 + fshift;
-                }
-            continue;
-        }
-#pragma unroll
-        for (int u = 0; u < Core::NUL; ++u)
-#pragma unroll
-            for (int q = 0; q < Core::RHOL; ++q) {
-                const int s = u * Core::RHOL + q;
-                const int n = Core::out_index(tid, u, q);
-                const float v4[4] = {zk[r][0][s].x, zk[r][0][s].y, zk[r][1][s].x, zk[r][1][s].y};
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    if (fallback) {
-                        a.dst_real[(size_t)(r0 + b) * L + n] = v4[b];
-#ifdef FDR_DEBUG_SKIP_MEM
-                    } else if (r0 + b < na.rows && n < na.cols && v4[b] == 1.2345e-30f) {
-#else
-                    } else if (r0 + b < na.rows && n < na.cols) {
-#endif
-                        const float p = v4[b] * fscale;
-                        na.out[(size_t)(r0 + b) * na.out_stride + n] = p + fshift;
-                    }
-                }
-            }
-    }
-    FDR_STAMP(na, w, 4);
-#ifdef FDR_DEBUG_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    FDR_STAMP(na, w, 5);
-#endif
-}
-
-// Repairs the rows of workgroups whose wait timed out in fft_rows4_inv_norm_kernel (normally none: every workgroup
-// returns after reading one word).  Same grid; by now every granule of this epoch is in memory.
-template <int LOGL, int R>
-__global__ __launch_bounds__(256) void normalize_fixup_kernel(const RowArgs a, const NormArgs na) {
-    using Geo = Rows4PackGeom<LOGL>;
-    constexpr int G = Geo::G, L = Steps<LOGL>::L;
-    const int w = blockIdx.x, nwg = gridDim.x;
-    if (na.fallback[w] == 0u) return;  // uniform
-    __shared__ float2 red[4];
-    float mn = __builtin_inff(), mx = -__builtin_inff();
-    for (int i = threadIdx.x; i < 2 * nwg; i += 256) {
-        const unsigned long long x = __hip_atomic_load(na.gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float v = __uint_as_float((unsigned)x);
-        if (i & 1) mx = fmaxf(mx, v); else mn = fminf(mn, v);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        mn = fminf(mn, __shfl_xor(mn, off));
-        mx = fmaxf(mx, __shfl_xor(mx, off));
-    }
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = make_float2(mn, mx);
-    __syncthreads();
-    mn = fminf(fminf(red[0].x, red[1].x), fminf(red[2].x, red[3].x));
-    mx = fmaxf(fmaxf(red[0].y, red[1].y), fmaxf(red[2].y, red[3].y));
-    float fscale, fshift;
-    minmax_to_scale_shift(mn, mx, fscale, fshift);
-    for (int r = 0; r < R; ++r)
-        for (int g = 0; g < G; ++g) {
-            const int r0 = ((r * nwg + w) * G + g) * 4;
-            for (int b = 0; b < 4; ++b) {
-                const int row = r0 + b;
-                if (row >= a.M || row >= na.rows) continue;
-                for (int n = threadIdx.x; n < na.cols; n += 256) {
-                    const float p = a.dst_real[(size_t)row * L + n] * fscale;
-                    na.out[(size_t)row * na.out_stride + n] = p + fshift;
-                }
-            }
-        }
-    __syncthreads();
-    if (threadIdx.x == 0) na.fallback[w] = 0u;
-}
-
 #ifndef FDR_ROWS_PERSISTENT
 #define FDR_ROWS_PERSISTENT 1
 #endif
@@ -1145,61 +904,6 @@ int rows4_minmax_partials(int logl, int M, int num_cu, int nimg) {
     return 0;
 }
 
-template <int LOGL>
-static int rows4_fused_geometry_t(int M, int num_cu, int* R, int* nwg) {
-    if constexpr (LOGL < 5 || LOGL > 12) {
-        return 0;  // half spectrum needs N >= 32; 8192-point rows leave no registers to keep results in
-    } else {
-        constexpr int G = Rows4PackGeom<LOGL>::G;
-        const int groups = (M + 3) / 4;
-        const int wg1 = (groups + G - 1) / G;           // workgroups at one row group per thread group
-        int r = (wg1 + num_cu - 1) / num_cu;
-        if (r == 3) r = 4;
-        if (r < 1 || r > 4 || num_cu <= 0) return 0;
-        *R = r;
-        *nwg = (groups + G * r - 1) / (G * r);           // <= num_cu: one workgroup per CU is always resident
-        return 1;
-    }
-}
-int rows4_fused_geometry(int logl, int M, int num_cu, int* R, int* nwg) {
-    FDR_DISPATCH_LOG(logl, rows4_fused_geometry_t<LG>(M, num_cu, R, nwg));
-    return 0;
-}
-
-template <int LOGL>
-static hipError_t launch_rows4_inv_norm_t(int R, int nwg, const RowArgs& a, const NormArgs& na, const float2* tw, hipStream_t s) {
-    if constexpr (LOGL < 5 || LOGL > 12) {
-        return hipErrorInvalidValue;
-    } else {
-        const dim3 grid(nwg), block(Rows4PackGeom<LOGL>::THREADS);
-        if (R == 1) hipLaunchKernelGGL((fft_rows4_inv_norm_kernel<LOGL, 1>), grid, block, 0, s, a, na, tw);
-        else if (R == 2) hipLaunchKernelGGL((fft_rows4_inv_norm_kernel<LOGL, 2>), grid, block, 0, s, a, na, tw);
-        else if (R == 4) hipLaunchKernelGGL((fft_rows4_inv_norm_kernel<LOGL, 4>), grid, block, 0, s, a, na, tw);
-        else return hipErrorInvalidValue;
-        return hipGetLastError();
-    }
-}
-hipError_t launch_rows4_inv_norm(int logl, int R, int nwg, const RowArgs& a, const NormArgs& na, const float2* tw_fwd, hipStream_t s) {
-    FDR_DISPATCH_LOG(logl, launch_rows4_inv_norm_t<LG>(R, nwg, a, na, tw_fwd, s));
-    return hipErrorInvalidValue;
-}
-
-template <int LOGL>
-static hipError_t launch_normalize_fixup_t(int R, int nwg, const RowArgs& a, const NormArgs& na, hipStream_t s) {
-    if constexpr (LOGL < 5 || LOGL > 12) {
-        return hipErrorInvalidValue;
-    } else {
-        if (R == 1) hipLaunchKernelGGL((normalize_fixup_kernel<LOGL, 1>), dim3(nwg), dim3(256), 0, s, a, na);
-        else if (R == 2) hipLaunchKernelGGL((normalize_fixup_kernel<LOGL, 2>), dim3(nwg), dim3(256), 0, s, a, na);
-        else if (R == 4) hipLaunchKernelGGL((normalize_fixup_kernel<LOGL, 4>), dim3(nwg), dim3(256), 0, s, a, na);
-        else return hipErrorInvalidValue;
-        return hipGetLastError();
-    }
-}
-hipError_t launch_normalize_fixup(int logl, int R, int nwg, const RowArgs& a, const NormArgs& na, hipStream_t s) {
-    FDR_DISPATCH_LOG(logl, launch_normalize_fixup_t<LG>(R, nwg, a, na, s));
-    return hipErrorInvalidValue;
-}
 
 // ---------------------------------------------------------------------------------------------
 // columns of one panel (contiguous M x 4 chunk)
@@ -1579,17 +1283,9 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
 
     // (Delaying the workgroup that landed in the odd wave slots by half a load phase, so that the two workgroups of
     // a CU alternate between memory and LDS phases, was measured: no gain up to 5 us of delay, slower beyond.)
-    const int wgid = img * ntiles + tl; (void)wgid;
-    FDR_STAMP(pb, wgid, 0);
     float2 v[4][V];
     tile_load<Core, false>(data, loff, 1u, v);
-    FDR_STAMP(pb, wgid, 1);
-#ifdef FDR_DEBUG_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    FDR_STAMP(pb, wgid, 2);
-#endif
     Core::template run<0, false>(v, grp_lds, tw_fwd, bases, tid);
-    FDR_STAMP(pb, wgid, 3);
 
     const bool packed_tile = packed0 && tl == 0;  // uniform per workgroup
     constexpr int SEQ = Core::SLOTS;
@@ -1673,7 +1369,6 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
             wmul(h + 1, wb);
         }
     }
-    FDR_STAMP(pb, wgid, 4);
     {
         // opaque copy of the thread index: the inverse transform's LDS addresses equal the forward transform's, and as
         // common subexpressions they would stay alive across the filter phase, where register pressure peaks
@@ -1682,14 +1377,7 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
         Core::permute_out_to_in(v);  // (a renaming of registers when the first and the last radix differ)
         Core::template run<SEQ, true>(v, grp_lds, tw_fwd, bases, ti);
     }
-    FDR_STAMP(pb, wgid, 5);
     if (active) tile_store<Core>(data, loff, v);
-    FDR_STAMP(pb, wgid, 6);
-#ifdef FDR_DEBUG_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    FDR_STAMP(pb, wgid, 7);
-    if (threadIdx.x == 0 && pb.stamps) pb.stamps[(size_t)wgid * 32 + 8] = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 4);
-#endif
 }
 
 template <int LOGM>

@@ -209,7 +209,7 @@ def test_committed_vectors_on_gpu(fdr):
 # ------------------------------------------------------------------------------------------------
 # fast-mode variants, batched mode, large sizes
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("flags_name", ["FLAG_SIMPLE_PATH", "FLAG_FULL_SPECTRUM", "FLAG_FUSED_NORM"])
+@pytest.mark.parametrize("flags_name", ["FLAG_SIMPLE_PATH", "FLAG_FULL_SPECTRUM"])
 @pytest.mark.parametrize("shape", [(200, 300), (1024, 1024)])
 def test_fast_variants_within_tolerance(fdr, oracle, flags_name, shape):
     psf = oracle.motion_blur_kernel(50, 30.0)
@@ -219,25 +219,6 @@ def test_fast_variants_within_tolerance(fdr, oracle, flags_name, shape):
         p.set_psf(psf, 0.01)
         got = p.wiener(img)
     assert np.abs(got - ref).max() <= TOL and np.linalg.norm(got - ref) / np.linalg.norm(ref) <= TOL
-
-
-@pytest.mark.parametrize("shape", [(32, 32), (100, 200), (256, 256), (500, 1000), (1024, 1024), (2048, 2048), (600, 4096)])
-@pytest.mark.parametrize("spin_limit", [None, 0])
-def test_fused_normalise_pass_equals_two_pass(fdr, oracle, shape, spin_limit):
-    """Pass C'+E fused (raw plane kept in registers across the grid-wide min/max hand-off) must give the bits of the
-    two-launch form; spin_limit "0" makes (nearly) every workgroup's wait time out, which exercises the fallback:
-    raw rows to HBM + the fix-up kernel."""
-    psf = oracle.motion_blur_kernel(15, 30.0)
-    img = _image(oracle, shape[0], shape[1], 77)
-    M, N = fdr.nextPowerOfTwo(shape[0]), fdr.nextPowerOfTwo(shape[1])
-    with fdr.Plan(M, N, fdr.MODE_FAST, flags=fdr.FLAG_FUSED_NORM) as p, fdr.Plan(M, N, fdr.MODE_FAST) as q:
-        if spin_limit is not None:
-            p.set_option(fdr.OPT_FUSED_SPIN_LIMIT, spin_limit)
-        p.set_psf(psf, 0.01)
-        q.set_psf(psf, 0.01)
-        for area in (fdr.NORM_PADDED, fdr.NORM_CROPPED):
-            for _ in range(2):  # second call: the granules of the first launch (older epoch) must not satisfy the wait
-                _assert_same(p.wiener(img, norm_area=area), q.wiener(img, norm_area=area), "fused vs two-pass, area %d" % area)
 
 
 @pytest.mark.parametrize("shape", [(32, 32), (30, 50), (100, 200), (256, 256), (500, 1000), (1024, 1024), (2000, 2048), (600, 4096), (37, 8100)])
