@@ -297,13 +297,17 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
         int rc = dft2d_dev(p, p->filt, p->work2, false, s);
         if (rc != FDR_OK) return rc;
     } else if (p->panel) {
+        // the PSF reaches only the first `prows` rows of the padded field: the row pass transforms just those row groups,
+        // the column pass takes every row below as zero (unread) and turns the spectrum into W on its way out
+        const int nvalid = (prows + 3) & ~3;  // <= M (M is a multiple of 8 on this path)
         RowArgs ra{};
         ra.src_real = d_psf; ra.src_rows = prows; ra.src_cols = pcols; ra.src_stride = pstride;
-        ra.dst_c = p->filt; ra.M = p->M; ra.pstride = p->pstride; ra.half = p->half; ra.num_cu = p->num_cu;
+        ra.dst_c = p->filt; ra.M = nvalid; ra.pstride = p->pstride; ra.half = p->half; ra.num_cu = p->num_cu;
         FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, ra, p->tw_row_f, s));
         ColArgs ca{};
         ca.data = p->filt; ca.N = p->N; ca.num_cu = p->num_cu; ca.pstride = p->pstride; ca.npanels = p->npanels;
-        FDR_HIP(launch_cols_panel(p->logM, COL_FWD, ca, p->tw_col_f, s));
+        ca.nvalid = nvalid; ca.K = K; ca.packed0 = p->half ? 1 : 0;
+        FDR_HIP(launch_cols_panel(p->logM, COL_FWD_FILTER, ca, p->tw_col_f, s));
     } else {
         RowArgs ra{};
         ra.src_real = d_psf; ra.src_rows = prows; ra.src_cols = pcols; ra.src_stride = pstride;
@@ -315,8 +319,8 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
     }
     if (p->mode == FDR_MODE_FAST && p->half)  // packed DC/Nyquist column: its slot values need H at k and M-k
         FDR_HIP(launch_filter_packed_column(p->filt, p->M, K, reinterpret_cast<float2*>(p->raw), s));
-    if (p->mode == FDR_MODE_FAST)
-        FDR_HIP(launch_make_filter_fast(p->filt, p->filt, p->panel ? (size_t)p->npanels * p->pstride : (size_t)p->M * p->N, K, s));
+    if (p->mode == FDR_MODE_FAST && !p->panel)  // (the panel path's column pass has written W already)
+        FDR_HIP(launch_make_filter_fast(p->filt, p->filt, (size_t)p->M * p->N, K, s));
     if (p->mode == FDR_MODE_FAST && p->half)
         FDR_HIP(launch_scatter_column(reinterpret_cast<const float2*>(p->raw), p->M, p->filt, s));
     p->K = K;

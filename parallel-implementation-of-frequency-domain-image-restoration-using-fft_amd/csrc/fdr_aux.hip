@@ -135,12 +135,7 @@ hipError_t launch_wiener_pointwise(float2* g, const float2* filt, size_t count, 
 __global__ void make_filter_fast_kernel(const float2* __restrict__ H, float2* __restrict__ W, size_t count, float K) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    const float2 h = H[i];
-    const double hr = h.x, hi = h.y;
-    const double denom = hr * hr + hi * hi + (double)K;
-    float2 w = make_float2(0.f, 0.f);
-    if (denom != 0.0) { w.x = (float)(hr / denom); w.y = (float)(-hi / denom); }
-    W[i] = w;
+    W[i] = wiener_filter_fast(H[i], K);
 }
 
 hipError_t launch_make_filter_fast(const float2* H, float2* W, size_t count, float K, hipStream_t s) {

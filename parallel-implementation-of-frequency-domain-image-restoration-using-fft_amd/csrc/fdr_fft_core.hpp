@@ -193,6 +193,16 @@ __device__ __forceinline__ float2 cmul_fma(float2 a, float2 w) {
 
 __device__ __forceinline__ void swap2(float2& a, float2& b) { const float2 t = a; a = b; b = t; }
 
+// fast mode: W = conj(H) / (|H|^2 + K), evaluated in double and rounded once (make_filter_fast_kernel and the fused
+// PSF column pass share this, so both give the same bits)
+__device__ __forceinline__ float2 wiener_filter_fast(float2 h, float K) {
+    const double hr = h.x, hi = h.y;
+    const double denom = hr * hr + hi * hi + (double)K;
+    float2 w = make_float2(0.f, 0.f);
+    if (denom != 0.0) { w.x = (float)(hr / denom); w.y = (float)(-hi / denom); }
+    return w;
+}
+
 // One radix-2^LR step on RHO = 2^LR values x[0..RHO) holding Y_s[r + R q][k], q = 0..RHO-1, leaving
 // Y_{s+LR}[r][k + LP q'] in x[q'].
 template <int LR, class Pol>

@@ -19,7 +19,8 @@ enum ColKind {
     COL_INV = 1,         // inverse column FFT, complex in place (fft2d)
     COL_FWD_WIENER = 2,  // parity pass B: forward column FFT then the Wiener quotient against H
     COL_INV_REAL = 3,    // parity pass D: inverse column FFT, real part to the raw plane, min/max
-    COL_FUSED = 4        // fast pass B' (panel kernels only): forward column FFT, multiply by W, inverse column FFT
+    COL_FUSED = 4,       // fast pass B' (panel kernels only): forward column FFT, multiply by W, inverse column FFT
+    COL_FWD_FILTER = 5   // PSF spectrum (panel kernels only): rows >= nvalid taken as zero, forward column FFT, W = conj(H)/(|H|^2+K)
 };
 
 // several images per launch of the fast row passes / the normalisation (blockIdx.y = image): small images are launch
@@ -75,6 +76,7 @@ struct ColArgs {
     int npanels;      // panel kernels: number of panels (0 = N/4)
     PanelBatch batch; // panel kernels, COL_FUSED: several images per launch
     int packed0;      // panel kernels: column 0 of panel 0 is the packed DC + i Nyquist column (half spectrum)
+    int nvalid;       // COL_FWD_FILTER: rows of the panels that hold data (a multiple of 4); the others are read as zero
     size_t pstride;   // panel kernels: panel stride in float2 elements
     int num_cu;       // CUs of the device (persistent pass B' launches one workgroup per CU)
 };
@@ -91,7 +93,7 @@ hipError_t launch_cols(int logm, int mode, ColKind kind, const ColArgs& a, const
 hipError_t launch_rows4(int logl, RowIn in, RowOut out, const RowArgs& a, const float2* tw_fwd, hipStream_t s);
 // min/max partials pass C' writes per image when `nimg` images share a launch on a device with num_cu CUs
 int rows4_minmax_partials(int logl, int M, int num_cu, int nimg);
-// cols_panel: COL_FWD (in place) or COL_FUSED (FFT . W . IFFT, persistent + register double-buffered)
+// cols_panel: COL_FWD_FILTER (PSF spectrum -> W, in place) or COL_FUSED (FFT . W . IFFT)
 hipError_t launch_cols_panel(int logm, ColKind kind, const ColArgs& a, const float2* tw_fwd, hipStream_t s);
 
 // reference-shaped and auxiliary kernels (fdr_aux.hip)

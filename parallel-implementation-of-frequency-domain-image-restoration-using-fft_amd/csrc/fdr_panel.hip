@@ -921,30 +921,6 @@ struct PanelGeom {
 
 // element offsets inside a panel: row m -> m*4 ; the uniform part (q) stays in SGPRs
 template <class Core>
-__device__ __forceinline__ void panel_load_in(const float2* __restrict__ pbase, int tid, float2 (&d)[4][8]) {
-#pragma unroll
-    for (int u = 0; u < Core::NU0; ++u) {
-        const unsigned toff = (unsigned)(tid + u * Core::T) * 4u;
-#pragma unroll
-        for (int q = 0; q < Core::RHO0; ++q) {
-            const int s = u * Core::RHO0 + q;
-            load4(pbase + ((size_t)(q << Core::LOGR0) * 4) + toff, d[0][s], d[1][s], d[2][s], d[3][s]);
-        }
-    }
-}
-template <class Core>
-__device__ __forceinline__ void panel_load_out(const float2* __restrict__ pbase, int tid, float2 (&d)[4][8]) {
-#pragma unroll
-    for (int u = 0; u < Core::NUL; ++u) {
-        const unsigned toff = (unsigned)(tid + u * Core::T) * 4u;
-#pragma unroll
-        for (int q = 0; q < Core::RHOL; ++q) {
-            const int s = u * Core::RHOL + q;
-            load4(pbase + ((size_t)(q << Core::LOGOUT) * 4) + toff, d[0][s], d[1][s], d[2][s], d[3][s]);
-        }
-    }
-}
-template <class Core>
 __device__ __forceinline__ void panel_store_out(float2* __restrict__ pbase, int tid, const float2 (&d)[4][8]) {
 #pragma unroll
     for (int u = 0; u < Core::NUL; ++u) {
@@ -957,10 +933,15 @@ __device__ __forceinline__ void panel_store_out(float2* __restrict__ pbase, int 
     }
 }
 
-// forward column FFT of every panel, in place (PSF spectrum)
+// forward column FFT of every panel, in place, for the fast path's PSF preparation: only the first
+// `nvalid` rows of a panel hold data -- the row pass before it transformed just the row groups the PSF reaches, everything
+// below is taken as zero without being read -- and the spectrum leaves as W = conj(H) / (|H|^2 + K) directly, except the
+// packed DC / Nyquist column (column 0 of panel 0, half spectrum), which filter_packed_column_kernel needs as raw H.
+// Against the separate row pass over all M rows + column pass + make_filter pass this drops 20 of 24 bytes per pixel.
 template <int LOGM>
-__global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PER_SIMD) void fft_cols_panel_fwd_kernel(
-    float2* __restrict__ data, const float2* __restrict__ tw_fwd, const size_t pstride, const int npanels) {
+__global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PER_SIMD) void fft_cols_panel_fwd_filter_kernel(
+    float2* __restrict__ data, const float2* __restrict__ tw_fwd, const size_t pstride, const int npanels, const int nvalid, const float K,
+    const int packed0) {
     using St = Steps<LOGM>;
     using Geo = PanelGeom<LOGM>;
     constexpr int G = Geo::G, T = St::T;
@@ -973,8 +954,24 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PE
     typename Core::Bases bases;
     Core::init_bases(bases, tw_fwd, tid);
     float2 v[4][8];
-    panel_load_in<Core>(pbase, tid, v);
+#pragma unroll
+    for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+        for (int q = 0; q < Core::RHO0; ++q) {
+            const int s = u * Core::RHO0 + q;
+            const int m = Core::in_index(tid, u, q);
+            if (m < nvalid) load4(pbase + (size_t)m * 4, v[0][s], v[1][s], v[2][s], v[3][s]);
+            else v[0][s] = v[1][s] = v[2][s] = v[3][s] = make_float2(0.f, 0.f);
+        }
     Core::template run<0, false>(v, lds + g * 2 * St::BUF, tw_fwd, bases, tid);
+    const bool raw0 = packed0 && p == 0;  // uniform per thread group
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (!raw0) v[0][s] = wiener_filter_fast(v[0][s], K);
+        v[1][s] = wiener_filter_fast(v[1][s], K);
+        v[2][s] = wiener_filter_fast(v[2][s], K);
+        v[3][s] = wiener_filter_fast(v[3][s], K);
+    }
     if (active) panel_store_out<Core>(pbase, tid, v);
 }
 
@@ -1386,8 +1383,9 @@ static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const floa
     const size_t ps = a.pstride;
     const int npanels = a.npanels > 0 ? a.npanels : a.N / 4;  // half spectrum: N/8
     const int ntiles = (npanels + Geo::G - 1) / Geo::G;
-    if (kind == COL_FWD) {
-        hipLaunchKernelGGL((fft_cols_panel_fwd_kernel<LOGM>), dim3(ntiles), dim3(Geo::THREADS), 0, s, a.data, tw, ps, npanels);
+    if (kind == COL_FWD_FILTER) {
+        hipLaunchKernelGGL((fft_cols_panel_fwd_filter_kernel<LOGM>), dim3(ntiles), dim3(Geo::THREADS), 0, s, a.data, tw, ps, npanels, a.nvalid, a.K,
+                           a.packed0);
     } else if (kind == COL_FUSED) {
         PanelBatch pb = a.batch;
         if (pb.nimg <= 0) { pb.nimg = 1; pb.data[0] = a.data; }
