@@ -317,12 +317,8 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
         ca.data = p->filt; ca.N = p->N;
         FDR_HIP(launch_cols(p->logM, p->mode, COL_FWD, ca, p->tw_col_f, p->tw_col_i, s));
     }
-    if (p->mode == FDR_MODE_FAST && p->half)  // packed DC/Nyquist column: its slot values need H at k and M-k
-        FDR_HIP(launch_filter_packed_column(p->filt, p->M, K, reinterpret_cast<float2*>(p->raw), s));
     if (p->mode == FDR_MODE_FAST && !p->panel)  // (the panel path's column pass has written W already)
         FDR_HIP(launch_make_filter_fast(p->filt, p->filt, (size_t)p->M * p->N, K, s));
-    if (p->mode == FDR_MODE_FAST && p->half)
-        FDR_HIP(launch_scatter_column(reinterpret_cast<const float2*>(p->raw), p->M, p->filt, s));
     p->K = K;
     p->have_psf = true;
     return FDR_OK;

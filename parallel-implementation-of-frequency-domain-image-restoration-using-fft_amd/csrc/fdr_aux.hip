@@ -143,36 +143,6 @@ hipError_t launch_make_filter_fast(const float2* H, float2* W, size_t count, flo
     return hipGetLastError();
 }
 
-// ---- half-spectrum mode: filter slot of the packed DC/Nyquist column (element stride 4 inside panel 0) ----
-__global__ void filter_packed_column_kernel(const float2* __restrict__ col0, int M, float K, float2* __restrict__ tmp) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= M) return;
-    const int j = k > M / 2 ? M - k : k;  // evaluate at j, store at k (S[k] = WN[M-k] for k > M/2)
-    const float2 c = col0[(size_t)j * 4], cm = col0[(size_t)((M - j) & (M - 1)) * 4];
-    const double h0r = 0.5 * ((double)c.x + cm.x), h0i = 0.5 * ((double)c.y - cm.y);   // H0 = (C + conj Cm)/2
-    const double hnr = 0.5 * ((double)c.y + cm.y), hni = 0.5 * ((double)cm.x - c.x);   // HN = (C - conj Cm)/(2i)
-    const double d0 = h0r * h0r + h0i * h0i + (double)K, dn = hnr * hnr + hni * hni + (double)K;
-    const double w0r = d0 != 0.0 ? h0r / d0 : 0.0, w0i = d0 != 0.0 ? -h0i / d0 : 0.0;
-    const double wnr = dn != 0.0 ? hnr / dn : 0.0, wni = dn != 0.0 ? -hni / dn : 0.0;
-    float2 s;
-    if (k == 0 || k == M / 2) s = make_float2((float)w0r, (float)wnr);
-    else if (k < M / 2) s = make_float2((float)w0r, (float)w0i);
-    else s = make_float2((float)wnr, (float)wni);
-    tmp[k] = s;
-}
-__global__ void scatter_column_kernel(const float2* __restrict__ tmp, int M, float2* __restrict__ col0) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < M) col0[(size_t)k * 4] = tmp[k];
-}
-hipError_t launch_filter_packed_column(const float2* Hcol0, int M, float K, float2* tmp, hipStream_t s) {
-    hipLaunchKernelGGL(filter_packed_column_kernel, dim3((M + 255) / 256), dim3(256), 0, s, Hcol0, M, K, tmp);
-    return hipGetLastError();
-}
-hipError_t launch_scatter_column(const float2* tmp, int M, float2* col0, hipStream_t s) {
-    hipLaunchKernelGGL(scatter_column_kernel, dim3((M + 255) / 256), dim3(256), 0, s, tmp, M, col0);
-    return hipGetLastError();
-}
-
 // ---- simple path: real plane + min/max (postprocess_kernel, fft/fft_gpu.cu:187-201, unscaled) ----
 __global__ void real_minmax_kernel(const float2* __restrict__ src, float* __restrict__ dst, int M, int N, int mm_rows,
                                    int mm_cols, float2* __restrict__ mm_part) {

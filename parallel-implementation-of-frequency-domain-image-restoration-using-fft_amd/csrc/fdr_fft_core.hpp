@@ -195,6 +195,23 @@ __device__ __forceinline__ void swap2(float2& a, float2& b) { const float2 t = a
 
 // fast mode: W = conj(H) / (|H|^2 + K), evaluated in double and rounded once (make_filter_fast_kernel and the fused
 // PSF column pass share this, so both give the same bits)
+// Filter slot S[k] of the packed DC / Nyquist column of the half spectrum (column 0 of panel 0 carries C = H0 + i HN with
+// H0 = H[., 0], HN = H[., N/2], both Hermitian along the column): ck = C[k], cmk = C[M - k].
+//   S[k] = W0[k] (0 < k < M/2),  S[k] = WN[M-k] (M/2 < k < M),  S[0] = (W0[0], WN[0]),  S[M/2] = (W0[M/2], WN[M/2])
+// with W = conj(H) / (|H|^2 + K) in double, rounded once; evaluated at j = min(k, M - k) (pass B' reads it that way).
+__device__ __forceinline__ float2 packed_column_filter_slot(float2 ck, float2 cmk, int k, int M, float K) {
+    const bool upper = k > M / 2;
+    const float2 c = upper ? cmk : ck, cm = upper ? ck : cmk;  // C[j], C[M - j]
+    const double h0r = 0.5 * ((double)c.x + cm.x), h0i = 0.5 * ((double)c.y - cm.y);   // H0 = (C + conj Cm)/2
+    const double hnr = 0.5 * ((double)c.y + cm.y), hni = 0.5 * ((double)cm.x - c.x);   // HN = (C - conj Cm)/(2i)
+    const double d0 = h0r * h0r + h0i * h0i + (double)K, dn = hnr * hnr + hni * hni + (double)K;
+    const double w0r = d0 != 0.0 ? h0r / d0 : 0.0, w0i = d0 != 0.0 ? -h0i / d0 : 0.0;
+    const double wnr = dn != 0.0 ? hnr / dn : 0.0, wni = dn != 0.0 ? -hni / dn : 0.0;
+    if (k == 0 || k == M / 2) return make_float2((float)w0r, (float)wnr);
+    if (k < M / 2) return make_float2((float)w0r, (float)w0i);
+    return make_float2((float)wnr, (float)wni);
+}
+
 __device__ __forceinline__ float2 wiener_filter_fast(float2 h, float K) {
     const double hr = h.x, hi = h.y;
     const double denom = hr * hr + hi * hi + (double)K;

@@ -103,10 +103,6 @@ hipError_t launch_simple_rows(float2* data, int rows, int L, int logl, const flo
 hipError_t launch_transpose(const float2* src, float2* dst, int rows, int cols, hipStream_t s);
 hipError_t launch_wiener_pointwise(float2* g, const float2* filt, size_t count, float K, int mode, hipStream_t s);
 hipError_t launch_make_filter_fast(const float2* H, float2* W, size_t count, float K, hipStream_t s);
-// half-spectrum mode: column 0 of panel 0 of the PSF spectrum is C = H0 + i HN (packed); build its filter slot
-// column (see packed_column_filter in fdr_panel.hip) into tmp[M], and scatter tmp back into the panel afterwards
-hipError_t launch_filter_packed_column(const float2* Hcol0, int M, float K, float2* tmp, hipStream_t s);
-hipError_t launch_scatter_column(const float2* tmp, int M, float2* col0, hipStream_t s);
 hipError_t launch_real_minmax(const float2* src, float* dst, int M, int N, int mm_rows, int mm_cols, float2* mm_part,
                               int* n_part, hipStream_t s);
 hipError_t launch_reduce_minmax(const float2* mm_part, int n_part, float* mm, hipStream_t s);

@@ -935,8 +935,8 @@ __device__ __forceinline__ void panel_store_out(float2* __restrict__ pbase, int 
 
 // forward column FFT of every panel, in place, for the fast path's PSF preparation: only the first
 // `nvalid` rows of a panel hold data -- the row pass before it transformed just the row groups the PSF reaches, everything
-// below is taken as zero without being read -- and the spectrum leaves as W = conj(H) / (|H|^2 + K) directly, except the
-// packed DC / Nyquist column (column 0 of panel 0, half spectrum), which filter_packed_column_kernel needs as raw H.
+// below is taken as zero without being read -- and the spectrum leaves as W = conj(H) / (|H|^2 + K) directly; the packed
+// DC / Nyquist column (column 0 of panel 0, half spectrum) leaves as its filter slots (packed_column_filter_slot).
 // Against the separate row pass over all M rows + column pass + make_filter pass this drops 20 of 24 bytes per pixel.
 template <int LOGM>
 __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PER_SIMD) void fft_cols_panel_fwd_filter_kernel(
@@ -965,6 +965,28 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PE
         }
     Core::template run<0, false>(v, lds + g * 2 * St::BUF, tw_fwd, bases, tid);
     const bool raw0 = packed0 && p == 0;  // uniform per thread group
+    if (packed0 && blockIdx.x == 0) {     // uniform per workgroup: the packed column's slots need C[k] and C[M - k]
+        float2* buf = lds + g * 2 * St::BUF;
+        __syncthreads();  // the transform's last exchange has been read by every wave
+        FDR_JITTER(4021);
+        if (raw0) {
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) buf[Core::out_index(tid, u, q)] = v[0][u * Core::RHOL + q];
+        }
+        __syncthreads();
+        FDR_JITTER(4022);
+        if (raw0) {
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int s = u * Core::RHOL + q, k = Core::out_index(tid, u, q);
+                    v[0][s] = packed_column_filter_slot(v[0][s], buf[(St::L - k) & (St::L - 1)], k, St::L, K);
+                }
+        }
+    }
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         if (!raw0) v[0][s] = wiener_filter_fast(v[0][s], K);
@@ -983,7 +1005,7 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::WAVES_PE
 // C[M-k] (one LDS round trip), filter each with its own W, and re-pack Z0 + i ZN; the inverse transform then
 // returns the two filtered real columns in the real and imaginary parts.  The filter slot of this column holds
 //   S[k] = W0[k] (0 < k < M/2),  S[k] = WN[M-k] (M/2 < k < M),  S[0] = (W0[0], WN[0]),  S[M/2] = (W0[M/2], WN[M/2])
-// (W0 = W[.,0], WN = W[.,N/2]; both Hermitian, their values at 0 and M/2 real), built by filter_packed_column_kernel.
+// (W0 = W[.,0], WN = W[.,N/2]; both Hermitian, their values at 0 and M/2 real), built by the PSF column pass (packed_column_filter_slot).
 template <int LOGM, class Core, int SEQ>
 __device__ __forceinline__ void packed_column_filter(float2 (&cur)[4][8], const float2 (&flt)[4][8], float2* grp_lds, int tid,
                                                      bool apply) {
