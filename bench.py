@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=96, help="images per GPU per step")
     ap.add_argument("--mode", choices=["fast", "parity"], default="fast")
     ap.add_argument("--streams", type=int, default=0, help="internal streams / workspaces the batch alternates over (0 = 2 in fast mode, 3 in parity mode)")
-    ap.add_argument("--group", type=int, default=0, help="images per pass-B' launch (fast mode; 1..4, streams*group <= 8; 0 = 4 up to 4096^2, else 2)")
+    ap.add_argument("--group", type=int, default=0, help="images per launch of every pass (fast mode; 1..8, streams*group <= 16; 0 = 8 up to 1024^2, 4 up to 4096^2, else 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals on a one-GPU box)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -153,12 +153,13 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     # measured best (tools/microbench/passbench, profiles/README.md): every pass runs 10-17 % faster per image when a
     # launch covers more than one image (launch gaps and the ramp-up / drain of a grid amortise; in pass B' the
-    # workgroups of one tile share its slice of the filter W in their XCD's L2), so images go in groups: up to 4096^2
-    # 2 streams x 4 images per launch, 8192^2 2 x 2 (24 x 8192^2: 3 x 2 145 k, 2 x 4 142 k, 2 x 2 150 k Mpixels/s)
+    # workgroups of one tile share its slice of the filter W in their XCD's L2), so images go in groups: up to 1024^2
+    # 2 streams x 8 images per launch (512^2: 56 k -> 89 k, 1024^2: 130 k -> 165 k Mpixels/s against 2 x 4), up to 4096^2
+    # 2 x 4, 8192^2 2 x 2 (24 x 8192^2: 3 x 2 145 k, 2 x 4 142 k, 2 x 2 150 k Mpixels/s)
     if args.streams <= 0:
         args.streams = 2 if args.mode == "fast" else 3
     if args.group <= 0:
-        args.group = 4 if S <= 4096 else 2
+        args.group = 8 if S <= 1024 else (4 if S <= 4096 else 2)
     plan.set_batching(args.streams, args.group if args.mode == "fast" else 1)
     plan.set_psf_motion(50, 30.0, 0.01, stream=stream)  # PSF generated, padded and transformed on the device
     imgs = torch.empty((max(B, 1), S, S), dtype=torch.float32, device=dev)

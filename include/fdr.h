@@ -143,9 +143,9 @@ int fdr_wiener_batch_ptrs_f32(fdr_plan* plan, const float* const* imgs_host, flo
  * so one image's kernel tails overlap the next image's kernel heads.  Costs (nstreams-1) extra
  * workspaces of 12 bytes per padded pixel.  Default 1.                                         */
 int fdr_plan_set_concurrency(fdr_plan* plan, int nstreams);
-/* The same with `group` (1..4) images per launch in the fast mode: every pass handles `group` images in one launch
- * (small images are launch bound; one launch per pass and group fills the chip).
- * nstreams * group <= 8 workspaces.  fdr_plan_set_concurrency(n) == fdr_plan_set_batching(n, 1).              */
+/* The same with `group` (1..8) images per launch in the fast mode: every pass handles `group` images in one launch
+ * (small images are launch bound; one launch per pass and group fills the chip; pass B' shares the filter between
+ * the images of a launch).  nstreams * group <= 16 workspaces.  fdr_plan_set_concurrency(n) == fdr_plan_set_batching(n, 1).              */
 int fdr_plan_set_batching(fdr_plan* plan, int nstreams, int group);
 
 /* -- fft_gpu::my_dft2D(Mat&, bool) (fft/fft.hpp:40; empty body at fft/fft_gpu.cu:515):

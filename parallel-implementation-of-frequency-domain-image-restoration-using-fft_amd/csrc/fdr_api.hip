@@ -154,7 +154,7 @@ struct fdr_plan {
         float2* work = nullptr; float2* work2 = nullptr; float* raw = nullptr; float* mm = nullptr; float2* mm_part = nullptr;
         hipStream_t stream = nullptr; hipEvent_t done = nullptr;
     };
-    static constexpr int kMaxSlots = 8;
+    static constexpr int kMaxSlots = 16;
     Slot slots[kMaxSlots];
     int nslots = 1;   // = nstreams * group
     int nstreams = 1;
@@ -225,20 +225,70 @@ const char* const kPassColsWiener = "B cols: FFT+Wiener";
 const char* const kPassRowsInv = "C rows: IFFT (complex)";
 const char* const kPassColsInvReal = "D cols: IFFT+real+minmax";
 const char* const kPassColsFused = "B' cols: FFT*W*IFFT";
-const char* const kPassColsFusedN[5] = {nullptr, kPassColsFused, "B' cols: FFT*W*IFFT [2 images]", "B' cols: FFT*W*IFFT [3 images]",
-                                       "B' cols: FFT*W*IFFT [4 images]"};
+const char* const kPassColsFusedN[kMaxGroup + 1] = {
+    nullptr,
+    kPassColsFused,
+    "B' cols: FFT*W*IFFT [2 images]",
+    "B' cols: FFT*W*IFFT [3 images]",
+    "B' cols: FFT*W*IFFT [4 images]",
+    "B' cols: FFT*W*IFFT [5 images]",
+    "B' cols: FFT*W*IFFT [6 images]",
+    "B' cols: FFT*W*IFFT [7 images]",
+    "B' cols: FFT*W*IFFT [8 images]"};
 const char* const kPassRowsInvReal = "C' rows: IFFT+real+minmax";
-const char* const kPassRowsFwdN[5] = {nullptr, nullptr, "A rows: pad+FFT (real->complex) [2 images]", "A rows: pad+FFT (real->complex) [3 images]",
-                                     "A rows: pad+FFT (real->complex) [4 images]"};
-const char* const kPassRowsInvRealN[5] = {nullptr, nullptr, "C' rows: IFFT+real+minmax [2 images]", "C' rows: IFFT+real+minmax [3 images]",
-                                         "C' rows: IFFT+real+minmax [4 images]"};
-const char* const kPassNormalizeN[5] = {nullptr, nullptr, "E normalize+crop [2 images]", "E normalize+crop [3 images]", "E normalize+crop [4 images]"};
+const char* const kPassRowsFwdN[kMaxGroup + 1] = {
+    nullptr,
+    nullptr,
+    "A rows: pad+FFT (real->complex) [2 images]",
+    "A rows: pad+FFT (real->complex) [3 images]",
+    "A rows: pad+FFT (real->complex) [4 images]",
+    "A rows: pad+FFT (real->complex) [5 images]",
+    "A rows: pad+FFT (real->complex) [6 images]",
+    "A rows: pad+FFT (real->complex) [7 images]",
+    "A rows: pad+FFT (real->complex) [8 images]"};
+const char* const kPassRowsInvRealN[kMaxGroup + 1] = {
+    nullptr,
+    nullptr,
+    "C' rows: IFFT+real+minmax [2 images]",
+    "C' rows: IFFT+real+minmax [3 images]",
+    "C' rows: IFFT+real+minmax [4 images]",
+    "C' rows: IFFT+real+minmax [5 images]",
+    "C' rows: IFFT+real+minmax [6 images]",
+    "C' rows: IFFT+real+minmax [7 images]",
+    "C' rows: IFFT+real+minmax [8 images]"};
+const char* const kPassNormalizeN[kMaxGroup + 1] = {
+    nullptr,
+    nullptr,
+    "E normalize+crop [2 images]",
+    "E normalize+crop [3 images]",
+    "E normalize+crop [4 images]",
+    "E normalize+crop [5 images]",
+    "E normalize+crop [6 images]",
+    "E normalize+crop [7 images]",
+    "E normalize+crop [8 images]"};
 const char* const kPassNormalize = "E normalize+crop";
 const char* const kPassRowsMinmax = "C1 rows: IFFT+minmax";
-const char* const kPassRowsMinmaxN[5] = {nullptr, nullptr, "C1 rows: IFFT+minmax [2 images]", "C1 rows: IFFT+minmax [3 images]", "C1 rows: IFFT+minmax [4 images]"};
+const char* const kPassRowsMinmaxN[kMaxGroup + 1] = {
+    nullptr,
+    nullptr,
+    "C1 rows: IFFT+minmax [2 images]",
+    "C1 rows: IFFT+minmax [3 images]",
+    "C1 rows: IFFT+minmax [4 images]",
+    "C1 rows: IFFT+minmax [5 images]",
+    "C1 rows: IFFT+minmax [6 images]",
+    "C1 rows: IFFT+minmax [7 images]",
+    "C1 rows: IFFT+minmax [8 images]"};
 const char* const kPassRowsNorm = "C2 rows: IFFT+normalize+crop";
-const char* const kPassRowsNormN[5] = {nullptr, nullptr, "C2 rows: IFFT+normalize+crop [2 images]", "C2 rows: IFFT+normalize+crop [3 images]",
-                                       "C2 rows: IFFT+normalize+crop [4 images]"};
+const char* const kPassRowsNormN[kMaxGroup + 1] = {
+    nullptr,
+    nullptr,
+    "C2 rows: IFFT+normalize+crop [2 images]",
+    "C2 rows: IFFT+normalize+crop [3 images]",
+    "C2 rows: IFFT+normalize+crop [4 images]",
+    "C2 rows: IFFT+normalize+crop [5 images]",
+    "C2 rows: IFFT+normalize+crop [6 images]",
+    "C2 rows: IFFT+normalize+crop [7 images]",
+    "C2 rows: IFFT+normalize+crop [8 images]"};
 const char* const kPassSimple = "simple path (reference-shaped)";
 
 int upload(float2** dst, const std::vector<float2>& v) {
@@ -391,7 +441,7 @@ int panel_stage_A_batch(fdr_plan* p, fdr_plan::Slot* const* ws, int n, const flo
     a.src_real = d_imgs[0]; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
     a.dst_c = ws[0]->work; a.M = p->M; a.pstride = p->pstride; a.half = 1; a.num_cu = p->num_cu;
     a.batch.nimg = n;
-    for (int k = 0; k < 4; ++k) { a.batch.src_real[k] = d_imgs[k < n ? k : 0]; a.batch.spec[k] = ws[k < n ? k : 0]->work; }
+    for (int k = 0; k < kMaxGroup; ++k) { a.batch.src_real[k] = d_imgs[k < n ? k : 0]; a.batch.spec[k] = ws[k < n ? k : 0]->work; }
     FDR_HIP(launch_rows4(p->logN, ROW_IN_REAL, ROW_OUT_COMPLEX, a, p->tw_row_f, s));
     return FDR_OK;
 }
@@ -405,7 +455,7 @@ int panel_stage_CE_batch(fdr_plan* p, fdr_plan::Slot* const* ws, int n, int rows
         a.n_part = rows4_minmax_partials(p->logN, p->M, p->num_cu, n);
         if (a.n_part <= 0 || a.n_part > p->mm_part_cap) return fail(FDR_ERR_STATE, "fdr_wiener: min/max partial count out of range");
         a.batch.nimg = n;
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kMaxGroup; ++k) {
             const fdr_plan::Slot* w = ws[k < n ? k : 0];
             a.batch.spec[k] = w->work; a.batch.mm_part[k] = w->mm_part; a.batch.out[k] = d_outs[k < n ? k : 0];
         }
@@ -425,7 +475,7 @@ int panel_stage_CE_batch(fdr_plan* p, fdr_plan::Slot* const* ws, int n, int rows
         a.src_c = ws[0]->work; a.dst_real = ws[0]->raw; a.mm_part = ws[0]->mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
         a.pstride = p->pstride; a.half = 1; a.num_cu = p->num_cu;
         a.batch.nimg = n;
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kMaxGroup; ++k) {
             const fdr_plan::Slot* w = ws[k < n ? k : 0];
             a.batch.spec[k] = w->work; a.batch.raw[k] = w->raw; a.batch.mm_part[k] = w->mm_part;
         }
@@ -437,7 +487,7 @@ int panel_stage_CE_batch(fdr_plan* p, fdr_plan::Slot* const* ws, int n, int rows
         if (n_part <= 0 || n_part > p->mm_part_cap || n_part > 4096) return fail(FDR_ERR_STATE, "fdr_wiener: min/max partial count out of range");
         NormBatch nb{};
         nb.nimg = n;
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kMaxGroup; ++k) {
             const fdr_plan::Slot* w = ws[k < n ? k : 0];
             nb.raw[k] = w->raw; nb.part[k] = w->mm_part; nb.out[k] = d_outs[k < n ? k : 0];
         }
@@ -823,7 +873,7 @@ int batch_enqueue(fdr_plan* p, const float* d_imgs, size_t img_pitch, int count,
             continue;
         }
         if (n > 1 && can_batch_rows(p)) {  // every pass once for the whole group
-            const float* ins[4]; float* outs[4];
+            const float* ins[kMaxGroup]; float* outs[kMaxGroup];
             for (int k = 0; k < n; ++k) { ins[k] = d_imgs + (size_t)(i0 + k) * img_pitch; outs[k] = d_out + (size_t)(i0 + k) * out_pitch; }
             rc = panel_stage_A_batch(p, ws, n, ins, rows, cols, stride, s);
             if (rc == FDR_OK) rc = panel_stage_B(p, ws, n, s);
@@ -856,8 +906,8 @@ extern "C" {
 
 int fdr_plan_set_batching(fdr_plan* p, int nstreams, int group) {
     if (!p) return fail(FDR_ERR_ARG, "fdr_plan_set_batching: null plan");
-    if (nstreams < 1 || group < 1 || group > 4 || nstreams * group > fdr_plan::kMaxSlots)
-        return fail(FDR_ERR_ARG, "fdr_plan_set_batching: need 1 <= group <= 4 and nstreams * group <= 8");
+    if (nstreams < 1 || group < 1 || group > kMaxGroup || nstreams * group > fdr_plan::kMaxSlots)
+        return fail(FDR_ERR_ARG, "fdr_plan_set_batching: need 1 <= group <= 8 and nstreams * group <= 16");
     FDR_HIP(hipSetDevice(p->device));
     if (!p->fork) FDR_HIP(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
     const int nslots = nstreams * group;
@@ -1295,10 +1345,10 @@ int batch_worker_run(const fdr_batch_desc* d, BatchWorker* w, std::chrono::stead
             return FDR_OK;
         }
         // synthetic, device resident
-        // defaults as bench.py's (measured): 2 streams; up to 4096^2 4 images per launch, larger 2
+        // defaults as bench.py's (measured): 2 streams; 8 images per launch up to 1024^2, 4 up to 4096^2, larger 2
         const size_t px = (size_t)d->M * (size_t)d->N;
         const int ns = d->nstreams > 0 ? d->nstreams : (d->mode == FDR_MODE_FAST ? 2 : 3);
-        const int gr = d->group > 0 ? d->group : (px <= (size_t)4096 * 4096 ? 4 : 2);
+        const int gr = d->group > 0 ? d->group : (px <= (size_t)1024 * 1024 ? 8 : (px <= (size_t)4096 * 4096 ? 4 : 2));
         r = fdr_plan_set_batching(plan, ns, d->mode == FDR_MODE_FAST ? gr : 1);
         if (r != FDR_OK) return r;
         const size_t P = (size_t)d->rows * d->cols, total = P * (size_t)w->count;

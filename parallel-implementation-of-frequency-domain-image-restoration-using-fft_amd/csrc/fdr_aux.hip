@@ -208,9 +208,9 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict_
                                                         int rows, int cols, int out_stride, const NormBatch nb) {
     if (nb.nimg > 1) {  // blockIdx.y = image
         const int i = blockIdx.y;
-        raw = i == 0 ? nb.raw[0] : i == 1 ? nb.raw[1] : i == 2 ? nb.raw[2] : nb.raw[3];
-        part = i == 0 ? nb.part[0] : i == 1 ? nb.part[1] : i == 2 ? nb.part[2] : nb.part[3];
-        out = i == 0 ? nb.out[0] : i == 1 ? nb.out[1] : i == 2 ? nb.out[2] : nb.out[3];
+        raw = pick_image(nb.raw, i);
+        part = pick_image(nb.part, i);
+        out = pick_image(nb.out, i);
     }
     __shared__ float2 red[4];
     float mn, mx;

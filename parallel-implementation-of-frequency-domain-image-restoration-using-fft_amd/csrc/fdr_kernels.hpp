@@ -25,18 +25,28 @@ enum ColKind {
 
 // several images per launch of the fast row passes / the normalisation (blockIdx.y = image): small images are launch
 // bound, one launch per pass and GROUP of images fills the chip.  nimg <= 1: the single-image fields are used.
+constexpr int kMaxGroup = 8;  // images per launch (fdr_plan_set_batching)
+// entry `i` (uniform over the workgroup) of a kernel-argument array as a select chain on scalars: a dynamic index would
+// send the array to scratch memory
+template <class P>
+__host__ __device__ __forceinline__ P pick_image(P const (&p)[kMaxGroup], int i) {
+    static_assert(kMaxGroup == 8, "select chain written for 8 entries");
+    const P lo = i == 0 ? p[0] : i == 1 ? p[1] : i == 2 ? p[2] : p[3];
+    const P hi = i == 4 ? p[4] : i == 5 ? p[5] : i == 6 ? p[6] : p[7];
+    return i < 4 ? lo : hi;
+}
 struct RowBatch {
-    const float* src_real[4];  // pass A input
-    float2* spec[4];           // pass A output / pass C' input (panel-major spectrum)
-    float* raw[4];             // pass C' output
-    float2* mm_part[4];        // pass C' min/max partials
-    float* out[4];             // pass C2 output (normalised, cropped)
+    const float* src_real[kMaxGroup];  // pass A input
+    float2* spec[kMaxGroup];           // pass A output / pass C' input (panel-major spectrum)
+    float* raw[kMaxGroup];             // pass C' output
+    float2* mm_part[kMaxGroup];        // pass C' min/max partials
+    float* out[kMaxGroup];             // pass C2 output (normalised, cropped)
     int nimg;
 };
 struct NormBatch {
-    const float* raw[4];
-    const float2* part[4];
-    float* out[4];
+    const float* raw[kMaxGroup];
+    const float2* part[kMaxGroup];
+    float* out[kMaxGroup];
     int nimg;
 };
 
@@ -59,9 +69,9 @@ struct RowArgs {
     RowBatch batch;     // rows4 packed kernels: several images per launch
 };
 
-// up to 4 images' spectra handled by ONE persistent pass-B' launch (their panels form one tile sequence)
+// up to kMaxGroup images' spectra handled by ONE pass-B' launch (their panels form one tile sequence)
 struct PanelBatch {
-    float2* data[4];
+    float2* data[kMaxGroup];
     int nimg;  // 0 or 1: use ColArgs::data only
 };
 

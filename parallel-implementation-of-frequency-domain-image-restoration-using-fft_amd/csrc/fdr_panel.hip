@@ -65,10 +65,6 @@ __device__ __forceinline__ void landed_f2(const float2 (&d)[R][C]) {
         for (int c = 0; c < C; c += 2) asm volatile("" ::"v"(d[r][c].x), "v"(d[r][c].y), "v"(d[r][c + 1].x), "v"(d[r][c + 1].y));
 }
 
-template <class P>
-__device__ __forceinline__ P pick4(P const (&p)[4], int i) {  // select chain: a dynamic index would send the kernarg array to scratch
-    return i == 0 ? p[0] : i == 1 ? p[1] : i == 2 ? p[2] : p[3];
-}
 
 // HALF: keep only the non-redundant half of each Hermitian row spectrum -- columns 0 .. N/2-1 in panels
 // 0 .. N/8-1.  X[m,0] and X[m,N/2] are real for a real row, so the Nyquist column rides in the imaginary
@@ -78,8 +74,8 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
                                                                                           const float2* __restrict__ tw_fwd) {
     RowArgs a = a0;
     if (a0.batch.nimg > 1) {  // blockIdx.y = image
-        a.src_real = pick4(a0.batch.src_real, blockIdx.y);
-        a.dst_c = pick4(a0.batch.spec, blockIdx.y);
+        a.src_real = pick_image(a0.batch.src_real, blockIdx.y);
+        a.dst_c = pick_image(a0.batch.spec, blockIdx.y);
     }
     using St = Steps<LOGL>;
     using Geo = Rows4PackGeom<LOGL>;
@@ -269,8 +265,8 @@ __global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<
     if (gi >= total) return;
     int img = 0, grp = gi;
     while (grp >= ngroups) { grp -= ngroups; ++img; }
-    auto src_of = [&](int im) -> const float* { return nimg > 1 ? pick4(a.batch.src_real, im) : a.src_real; };
-    auto dst_of = [&](int im) -> float2* { return nimg > 1 ? pick4(a.batch.spec, im) : a.dst_c; };
+    auto src_of = [&](int im) -> const float* { return nimg > 1 ? pick_image(a.batch.src_real, im) : a.src_real; };
+    auto dst_of = [&](int im) -> float2* { return nimg > 1 ? pick_image(a.batch.spec, im) : a.dst_c; };
 
     // four image rows of group `g` of image `im`: unconditional loads from clamped coordinates; scale = 0 collapses
     // every address onto element 0 of the image (a prefetch with nothing to fetch: conditional loads would make the
@@ -658,10 +654,10 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_pa
                                                                                           const float2* __restrict__ tw_fwd) {
     RowArgs a = a0;
     if (a0.batch.nimg > 1) {  // blockIdx.y = image
-        a.src_c = pick4(a0.batch.spec, blockIdx.y);
-        if constexpr (OUT == 0) a.dst_real = pick4(a0.batch.raw, blockIdx.y);
-        if constexpr (OUT == 2) a.out = pick4(a0.batch.out, blockIdx.y);
-        a.mm_part = pick4(a0.batch.mm_part, blockIdx.y);
+        a.src_c = pick_image(a0.batch.spec, blockIdx.y);
+        if constexpr (OUT == 0) a.dst_real = pick_image(a0.batch.raw, blockIdx.y);
+        if constexpr (OUT == 2) a.out = pick_image(a0.batch.out, blockIdx.y);
+        a.mm_part = pick_image(a0.batch.mm_part, blockIdx.y);
     }
     float fscale = 0.f, fshift = 0.f;
     using St = Steps<LOGL>;
@@ -710,10 +706,10 @@ __global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<
     const RowArgs a0, const float2* __restrict__ tw_fwd, const int ngroups) {
     RowArgs a = a0;
     if (a0.batch.nimg > 1) {  // blockIdx.y = image
-        a.src_c = pick4(a0.batch.spec, blockIdx.y);
-        if constexpr (OUT == 0) a.dst_real = pick4(a0.batch.raw, blockIdx.y);
-        if constexpr (OUT == 2) a.out = pick4(a0.batch.out, blockIdx.y);
-        a.mm_part = pick4(a0.batch.mm_part, blockIdx.y);
+        a.src_c = pick_image(a0.batch.spec, blockIdx.y);
+        if constexpr (OUT == 0) a.dst_real = pick_image(a0.batch.raw, blockIdx.y);
+        if constexpr (OUT == 2) a.out = pick_image(a0.batch.out, blockIdx.y);
+        a.mm_part = pick_image(a0.batch.mm_part, blockIdx.y);
     }
     float fscale = 0.f, fshift = 0.f;
     if constexpr (OUT == 2) block_fold_partials(a.mm_part, a.n_part, fscale, fshift);
@@ -1205,7 +1201,7 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::PIPE_WAV
         r.ok = tl * G + g < npanels;
         r.loff = (r.ok ? (unsigned)g : 0u) * pstride + (unsigned)tid * 4u;
         const size_t tbase = (size_t)(tl * G) * pstride;
-        r.data = (img == 0 ? pb.data[0] : img == 1 ? pb.data[1] : img == 2 ? pb.data[2] : pb.data[3]) + tbase;
+        r.data = pick_image(pb.data, img) + tbase;
         r.filt = filt + tbase;
         return r;
     };
@@ -1281,7 +1277,7 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
     const int tid = Core::thread_index(threadIdx.x & (T - 1));
     float2* grp_lds = lds + g * 2 * St::BUF;
     // Two mappings of workgroups to (tile, image), both free of integer divisions (which would run on the VALU and drag
-    // every tile address into VGPRs).  img_shift < 0: grid (ntiles, images).  Otherwise (2 or 4 images, tiles a multiple
+    // every tile address into VGPRs).  img_shift < 0: grid (ntiles, images).  Otherwise (2, 4 or 8 images, tiles a multiple
     // of 8): a flat grid in which the workgroups that share a tile -- and so its slice of the filter W -- are neighbours
     // on the SAME XCD (workgroup b lands on XCD b % 8), so W crosses the fabric once per tile, not once per image.
     int img, tl;
@@ -1293,7 +1289,7 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
     }
     const bool active = tl * G + g < npanels;
     const size_t tbase = (size_t)(tl * G) * pstride;
-    float2* __restrict__ data = (img == 0 ? pb.data[0] : img == 1 ? pb.data[1] : img == 2 ? pb.data[2] : pb.data[3]) + tbase;
+    float2* __restrict__ data = pick_image(pb.data, img) + tbase;
     const float2* __restrict__ tfilt = filt + tbase;
     const unsigned loff = (active ? (unsigned)g : 0u) * pstride + (unsigned)tid * 4u;
 
@@ -1411,11 +1407,11 @@ static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const floa
     } else if (kind == COL_FUSED) {
         PanelBatch pb = a.batch;
         if (pb.nimg <= 0) { pb.nimg = 1; pb.data[0] = a.data; }
-        for (int k = pb.nimg; k < 4; ++k) pb.data[k] = pb.data[0];
+        for (int k = pb.nimg; k < kMaxGroup; ++k) pb.data[k] = pb.data[0];
         if constexpr (LOGM >= 10) {  // 16 values per thread: one workgroup per tile, grid (tiles, images)
             using G16 = Panel16Geom<LOGM>;
             const int nt16 = (npanels + G16::G - 1) / G16::G;
-            const int ishift = FDR_SHARE_W && (nt16 % 8 == 0) ? (pb.nimg == 2 ? 1 : pb.nimg == 4 ? 2 : -1) : -1;
+            const int ishift = FDR_SHARE_W && (nt16 % 8 == 0) ? (pb.nimg == 2 ? 1 : pb.nimg == 4 ? 2 : pb.nimg == 8 ? 3 : -1) : -1;
             const dim3 grid16 = ishift < 0 ? dim3(nt16, pb.nimg) : dim3(nt16 * pb.nimg);
             hipLaunchKernelGGL((fft_cols_panel_fused16_kernel<LOGM>), grid16, dim3(G16::THREADS), 0, s, pb, a.filt, tw,
                                (unsigned)ps, npanels, nt16, a.packed0, ishift);

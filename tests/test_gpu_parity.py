@@ -171,7 +171,7 @@ def test_errors(fdr):
         with pytest.raises(fdr.FdrError):
             p.wiener_batch(np.zeros((2, 65, 64), np.float32))  # host batch: the same shape check
         assert p.wiener_batch(np.zeros((0, 64, 64), np.float32)).shape == (0, 64, 64)  # empty batch is a no-op
-        for bad in ((0, 1), (1, 0), (1, 5), (3, 3), (9, 1)):  # streams * group <= 8, group <= 4
+        for bad in ((0, 1), (1, 0), (1, 9), (3, 6), (17, 1)):  # streams * group <= 16, group <= 8
             with pytest.raises(fdr.FdrError):
                 p.set_batching(*bad)
         p.set_batching(2, 4)
@@ -241,7 +241,7 @@ def test_two_sweep_normalisation_equals_raw_plane_passes(fdr, oracle, shape):
         q.set_psf(psf, 0.01)
         for area in (fdr.NORM_PADDED, fdr.NORM_CROPPED):
             _assert_same(p.wiener(host[0], norm_area=area), q.wiener(host[0], norm_area=area), "two-sweep vs raw plane, area %d" % area)
-            for nstreams, group in ((1, 4), (2, 2), (1, 3)):
+            for nstreams, group in ((1, 4), (2, 2), (1, 3), (1, 5)):
                 outs = []
                 for plan in (p, q):
                     d_o = torch.full_like(d_in, -1.0)
@@ -357,7 +357,7 @@ def test_batched_multistream_equals_one_by_one(fdr, oracle, mode_name):
         p.set_concurrency(3)
         p.wiener_batch_dev(d_in.data_ptr(), rows * cols, B, rows, cols, cols, d_out3.data_ptr(), rows * cols, cols, stream=s)
         torch.cuda.synchronize()
-        for nstreams, group in ((1, 2), (2, 2), (2, 3), (1, 4)):  # several images per pass-B' launch (fast mode)
+        for nstreams, group in ((1, 2), (2, 2), (2, 3), (1, 4), (1, 5), (2, 8)):  # several images per pass-B' launch (fast mode)
             d_g = torch.zeros_like(d_in)
             p.set_batching(nstreams, group)
             p.wiener_batch_dev(d_in.data_ptr(), rows * cols, B, rows, cols, cols, d_g.data_ptr(), rows * cols, cols, stream=s)
@@ -386,7 +386,7 @@ def test_grouped_long_column_launches_equal_one_by_one(fdr, oracle, shape):
     with fdr.Plan(M, N, fdr.MODE_FAST) as p:
         p.set_psf(psf, 0.01)
         one = np.stack([p.wiener(host[i]) for i in range(B)])
-        for nstreams, group in ((1, 2), (2, 2), (1, 3), (1, 4), (2, 4)):  # 7 = 2+2+2+1 = 3+3+1 = 4+3
+        for nstreams, group in ((1, 2), (2, 2), (1, 3), (1, 4), (2, 4), (1, 6), (1, 8)):  # 7 = 2+2+2+1 = 3+3+1 = 4+3 = 6+1 = 7
             d_g = torch.zeros_like(d_in)
             p.set_batching(nstreams, group)
             p.wiener_batch_dev(d_in.data_ptr(), rows * cols, B, rows, cols, cols, d_g.data_ptr(), rows * cols, cols, stream=s)
@@ -406,7 +406,7 @@ def test_overlapping_streams_equal_one_by_one_every_image(fdr, oracle, shape, mo
     batching, several repetitions, against the one-by-one result -- bit for bit."""
     import torch
     rows, cols = shape
-    B, reps = 8, 6
+    B, reps = 12, 5
     M, N = fdr.nextPowerOfTwo(rows), fdr.nextPowerOfTwo(cols)
     host = np.stack([_image(oracle, rows, cols, 700 + i) for i in range(B)])
     d_in = torch.from_numpy(host).cuda()
@@ -420,7 +420,7 @@ def test_overlapping_streams_equal_one_by_one_every_image(fdr, oracle, shape, mo
             p.set_option(fdr.OPT_TWO_SWEEP_NORM, two)
             p.set_psf_motion(15, 30.0, 0.01)
             one = np.stack([p.wiener(host[i]) for i in range(B)])
-            for ns, gr in ((2, 1), (3, 1), (2, 2), (3, 2), (2, 4)):
+            for ns, gr in ((2, 1), (3, 1), (2, 2), (3, 2), (2, 4), (2, 8)):
                 if mode == fdr.MODE_PARITY and gr > 1:
                     continue
                 p.set_batching(ns, gr)
