@@ -23,7 +23,7 @@ for rows, cols in shapes:
             p.set_option(fdr.OPT_TWO_SWEEP_NORM, two)
             p.set_psf_motion(15 if min(rows, cols) >= 32 else 5, 30.0, 0.01)
             one = np.stack([p.wiener(host[i]) for i in range(B)])
-            for ns, gr in ((2, 1), (3, 1), (2, 2), (3, 2), (2, 4), (2, 3)):
+            for ns, gr in ((2, 1), (3, 1), (2, 2), (3, 2), (2, 4), (2, 3), (2, 8)):
                 fails = {}
                 p.set_batching(ns, gr)
                 for rep in range(reps):
