@@ -12,7 +12,10 @@ scaling (per-GPU batch fixed).  Rank 0 prints ONE JSON line.
 The JSON line also carries
   roofline     : algorithmic bytes of the dominant kernel / its mean duration, measured with hipEvent
                  pairs on the launch stream over a repetition of the same K steps (the timed region
-                 itself is left un-instrumented), against the 8 TB/s HBM peak;
+                 itself is left un-instrumented), against the 8 TB/s HBM peak.  The formulation is the
+                 HALF spectrum (32 B/pixel), and a pass-B' launch of n images counts the
+                 filter W ONCE (8 n + 4 B/pixel): `frac` is a bandwidth fraction, `frac_by_counters`
+                 the same from the PMC bytes of profiles/traffic.json;
   cpu_baseline : the CPU oracle (oracle/, a restatement of the reference's serial path) timed on one
                  host core on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -49,6 +52,27 @@ PIPELINE_BYTES = {("fast", "half"): 36, ("fast", "full"): 56, ("parity", "full")
 SEEDS = {1024: 0x5EED0002, 4096: 0x5EED0003, 8192: 0x5EED0004, 2048: 0x5EED0005}
 
 
+def split_pass_name(name):
+    """'B' cols: FFT*W*IFFT [4 images]' -> ("B' cols: FFT*W*IFFT", 4)"""
+    if name.endswith(" images]"):
+        base, tail = name.rsplit(" [", 1)
+        return base, int(tail.split()[0])
+    return name, 1
+
+
+def pass_bytes_per_launch(name, spectrum, P):
+    """Algorithmic HBM bytes of ONE launch of pass `name` (which may cover several images).  Pass B' reads the filter W once
+    per launch, not once per image: the workgroups that handle one tile for the n images of a launch are neighbours on one
+    XCD and share the tile's slice of W in its L2 (the PMC traffic confirms it), so a launch moves
+    n x (spectrum in + out) + 1 x W."""
+    base, nimg = split_pass_name(name)
+    bpp = PASS_BYTES[spectrum].get(base, 0)
+    if base.startswith("B' cols"):
+        w = 4 if spectrum == "half" else 8
+        return ((bpp - w) * nimg + w) * P, nimg
+    return bpp * P * nimg, nimg
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +93,10 @@ def parse():
                          "(fft/fft_mpi.cpp:89-100), e.g. BASELINE config 5: --size 2048 --total-batch 512; 0 = weak scaling with --batch per GPU")
     ap.add_argument("--raw-plane", action="store_true", help="passes C' + E (raw real plane, 36 B/pixel) instead of the two-sweep C1 + C2 (32 B/pixel)")
     ap.add_argument("--no-psf-recompute", action="store_true", help="skip the second figure (PSF spectrum rebuilt per image)")
+    ap.add_argument("--no-parity-leg", action="store_true", help="skip config.value_parity_mode (a short timed leg in the bit-identical mode)")
+    ap.add_argument("--bcast-filter", action="store_true",
+                    help="rank 0 alone prepares the PSF spectrum / filter W and broadcasts it (RCCL under nccl) instead of every rank "
+                         "recomputing it: the MPI_Bcast / Scatterv of the padded PSF in the reference's MPI variant (fft/fft_mpi.cpp:334-378)")
     return ap.parse_args()
 
 
@@ -161,7 +189,30 @@ def main():
     if args.group <= 0:
         args.group = 8 if S <= 1024 else (4 if S <= 4096 else 2)
     plan.set_batching(args.streams, args.group if args.mode == "fast" else 1)
-    plan.set_psf_motion(50, 30.0, 0.01, stream=stream)  # PSF generated, padded and transformed on the device
+    bcast = None
+    if args.bcast_filter:
+        # ONE rank prepares the filter, the others receive its bytes: dist.broadcast of the plan's filter block (RCCL over
+        # xGMI under "nccl"); every rank then hashes the filter it holds and the end-of-run all-reduce proves they are rank
+        # 0's bits.  Default stays local recompute (cheaper than the broadcast).
+        nbytes = plan.filter_bytes()
+        wbuf = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
+        if rank == 0:
+            plan.set_psf_motion(50, 30.0, 0.01, stream=stream)
+            plan.export_filter_dev(wbuf.data_ptr(), nbytes, stream=stream)
+        t0b = time.perf_counter()
+        comm.broadcast(wbuf, src=0)
+        torch.cuda.synchronize()
+        bcast_s = time.perf_counter() - t0b
+        if rank != 0:
+            plan.import_filter_dev(wbuf.data_ptr(), nbytes, 0.01, stream=stream)
+        chk_buf = torch.empty_like(wbuf)
+        plan.export_filter_dev(chk_buf.data_ptr(), nbytes, stream=stream)  # what the plan really holds now
+        torch.cuda.synchronize()
+        whash = int(chk_buf.to(torch.int64).sum().item()) & ((1 << 52) - 1)
+        bcast = {"bytes": nbytes, "seconds": bcast_s, "hash": whash}
+        del wbuf, chk_buf
+    else:
+        plan.set_psf_motion(50, 30.0, 0.01, stream=stream)  # PSF generated, padded and transformed on the device
     imgs = torch.empty((max(B, 1), S, S), dtype=torch.float32, device=dev)
     outs = torch.zeros((max(B, 1), S, S), dtype=torch.float32, device=dev)
     # image b of this rank is global image first_image + b of the counter-based generator (distinct per rank)
@@ -191,19 +242,23 @@ def main():
         # every image is min-max normalised over its whole (padded = full) plane: each must span [0, 1]
         spans = bool(((outs[:B].amin(dim=(1, 2)) <= 1e-6) & (outs[:B].amax(dim=(1, 2)) > 1.0 - 1e-6)).all().item())
         # the overlapped, grouped batch must give the bits of the one-image-at-a-time path (one stream, one image per
-        # launch): a sample of images spread over the batch, including the last one
-        sample = sorted({0, 1, B // 3, B // 2, (2 * B) // 3, B - 2, B - 1} & set(range(B)))
+        # launch) for EVERY image of the step (round 2's LDS race lived in the images nobody compared): one extra pass
+        # outside the timed region, compared on the device
         one = torch.empty((S, S), dtype=torch.float32, device=dev)
-        same = True
-        for k in sample:
+        differing = []
+        for k in range(B):
             plan.wiener_dev(imgs[k].data_ptr(), S, S, S, one.data_ptr(), S, fdr.NORM_PADDED, stream=stream)
-            torch.cuda.synchronize()
-            same = same and bool(torch.equal(one, outs[k]))
+            if not bool(torch.equal(one, outs[k])):
+                differing.append(k)
         del one
+        same = not differing
         ok = finite and omin >= 0.0 and omax <= 1.0 and spans and same
     else:
-        chk, ok, sample = 0.0, True, []
+        chk, ok, differing = 0.0, True, []
     tot = comm.allreduce_sum([images_mine, chk, 1.0 if ok else 0.0, B])
+    if bcast is not None:  # every rank's filter hash must be rank 0's
+        bcast["hash_min"], bcast["hash_max"] = int(comm.allreduce_min(bcast["hash"])), int(comm.allreduce_max(bcast["hash"]))
+        bcast["seconds_max"] = comm.allreduce_max(bcast["seconds"])
     out0 = outs[0].cpu().numpy() if (rank == 0 and B > 0) else None
 
     # ---- second figure: the PSF spectrum rebuilt for every image, as the reference's loop does per channel
@@ -220,6 +275,25 @@ def main():
         psf_elapsed = batch_mod.timed_steps(comm, step_psf, torch.cuda.synchronize, args.steps, 1)
         psf_images = comm.allreduce_sum([nb * args.steps])[0]
 
+    # ---- third figure: the bit-identical mode (FDR_MODE_PARITY: reference pass order, 72 B/pixel, 5 launches) on a bounded leg ----
+    parity_elapsed, parity_images = None, 0
+    if not args.no_parity_leg and args.mode == "fast":
+        nbp = min(B, 12 if S <= 4096 else 4)
+        psteps = max(1, min(args.steps, 4))
+        pplan = fdr.Plan(S, S, fdr.MODE_PARITY, device=local_rank)
+        pplan.set_batching(3, 1)
+        pplan.set_psf_motion(50, 30.0, 0.01, stream=stream)
+        pouts = torch.empty((max(nbp, 1), S, S), dtype=torch.float32, device=dev)
+
+        def step_parity():
+            if nbp > 0:
+                pplan.wiener_batch_dev(imgs.data_ptr(), P, nbp, S, S, S, pouts.data_ptr(), P, S, fdr.NORM_PADDED, stream=stream)
+
+        parity_elapsed = batch_mod.timed_steps(comm, step_parity, torch.cuda.synchronize, psteps, 1)
+        parity_images = comm.allreduce_sum([nbp * psteps])[0]
+        pplan.close()
+        del pouts
+
     # ---- per-kernel durations: hipEvent pairs on the launch stream, same K steps again (one stream: un-overlapped) ----
     plan.profile(True)
     for _ in range(args.steps):
@@ -232,33 +306,41 @@ def main():
     if rank == 0:
         images = int(tot[0])
         value = images * P / 1e6 / elapsed
-        # bytes per pixel of the passes that actually ran (the fused C'E pass drops the raw-plane round trip)
-        base_names = {n.rsplit(" [", 1)[0] if n.endswith(" images]") else n for n, _, _ in passes}
-        pipe_bpp = sum(PASS_BYTES[spectrum].get(n, 0) for n in base_names) or PIPELINE_BYTES[(args.mode, spectrum)]
+        # bytes per pixel of the passes that actually ran, per image, with W counted once per pass-B' launch
+        per_image_bytes = 0.0
+        for n, _, _ in passes:
+            bl, ni = pass_bytes_per_launch(n, spectrum, P)
+            per_image_bytes += bl / ni
+        pipe_bpp = per_image_bytes / P if per_image_bytes else float(PIPELINE_BYTES[(args.mode, spectrum)])
         pipe_gbps = pipe_bpp * P * images / elapsed / 1e9
         dom = max(passes, key=lambda t: t[1]) if passes else None  # longest launch
         roofline = None
         if dom:
             name, ms, cnt = dom
-            # a grouped launch ("... [k images]") moves k images' worth of bytes
-            base_name, nimg = name, 1
-            if name.endswith(" images]"):
-                base_name, tail = name.rsplit(" [", 1)
-                nimg = int(tail.split()[0])
-            alg = PASS_BYTES[spectrum].get(base_name, 0) * P * nimg
+            base_name, nimg = split_pass_name(name)
+            alg, _ = pass_bytes_per_launch(name, spectrum, P)
             achieved = alg / (ms * 1e-3) / 1e9
+            per_image_equiv = PASS_BYTES[spectrum].get(base_name, 0) * P * nimg  # every image counted with its own W
+            all_frac = {}
+            for n, m, _ in passes:
+                if m > 0:
+                    all_frac[n] = round(pass_bytes_per_launch(n, spectrum, P)[0] / (m * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
             roofline = {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "frac_by_counters": None,
                 "kernel": name, "kernel_ms": round(ms, 5), "launches_timed": cnt,
                 "algorithmic_bytes_per_launch": alg,
+                "formulation": ("%s spectrum%s; W counted once per pass-B' launch of n images ((8 n + 4) B/px in the half spectrum)"
+                                % (spectrum, ", 32 B/px per image (SURVEY 8f-4), not the 56 B/px complex-to-complex count of SURVEY 8d"
+                                   if spectrum == "half" else "")),
+                "per_image_equivalent": {"note": "the same launch with W counted once per IMAGE (12 B/px in pass B'): bytes a one-image launch "
+                                                 "would move, NOT bandwidth", "bytes_per_launch": per_image_equiv,
+                                         "GBps": round(per_image_equiv / (ms * 1e-3) / 1e9, 1)},
                 "all_passes_ms": {n: round(m, 5) for n, m, _ in passes},
-                "all_passes_frac": {n: round(PASS_BYTES[spectrum].get(n.rsplit(" [", 1)[0] if n.endswith(" images]") else n, 0) * P
-                                             * (int(n.rsplit(" [", 1)[1].split()[0]) if n.endswith(" images]") else 1)
-                                             / (m * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) for n, m, _ in passes if m > 0},
-                "pipeline": {"bytes_per_pixel": pipe_bpp, "achieved": round(pipe_gbps, 1),
+                "all_passes_frac": all_frac,
+                "pipeline": {"bytes_per_pixel": round(pipe_bpp, 3), "achieved": round(pipe_gbps, 1),
                              "frac": round(pipe_gbps / HBM_PEAK_GBPS, 4),
-                             "full_complex_equivalent_GBps": round(PIPELINE_BYTES[(args.mode, "full")] * P * images / elapsed / 1e9, 1)},
+                             "c2c_56_Bpx_would_need_GBps": round(PIPELINE_BYTES[(args.mode, "full")] * P * images / elapsed / 1e9, 1)},
             }
             tfile = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tfile):
@@ -267,9 +349,17 @@ def main():
                     key = "%s/%s/%d" % (args.mode, spectrum, S)
                     if key in tj and base_name in tj[key]:
                         ent = tj[key][base_name]  # PMC bytes per launch of `images` images (tools/summarize_profiles.py)
-                        roofline["traffic"] = ent["per_launch"] * nimg / ent["images"] if isinstance(ent, dict) else ent * nimg
-                        if isinstance(ent, dict) and ent["images"] != nimg:
+                        if isinstance(ent, dict) and ent["images"] == nimg:
+                            roofline["traffic"] = ent["per_launch"]
+                        elif isinstance(ent, dict):
+                            # a launch of another size was profiled: scale the per-image part, keep W once (pass B')
+                            w_once = (4 if spectrum == "half" else 8) * P if base_name.startswith("B' cols") else 0
+                            roofline["traffic"] = (ent["per_launch"] - w_once) * nimg / ent["images"] + w_once
                             roofline["traffic_note"] = "scaled from a %d-image launch" % ent["images"]
+                        else:
+                            roofline["traffic"] = ent * nimg
+                        roofline["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x 2 on gfx950)"
+                        roofline["frac_by_counters"] = round(roofline["traffic"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
                 except Exception:
                     pass
         vals = sorted(images * P / 1e6 / t for t in reps)
@@ -280,7 +370,11 @@ def main():
                   "parallelism": "images sharded over %d rank(s), no data-path collective" % world,
                   "normalize_area": "padded (serial semantics)",
                   "repeats": len(reps), "value_min": round(vals[0], 1), "value_max": round(vals[-1], 1),
-                  "value_with_psf_recompute": round(psf_images * P / 1e6 / psf_elapsed, 1) if (psf_elapsed and psf_images) else None}
+                  "value_with_psf_recompute": round(psf_images * P / 1e6 / psf_elapsed, 1) if (psf_elapsed and psf_images) else None,
+                  "value_parity_mode": round(parity_images * P / 1e6 / parity_elapsed, 1) if (parity_elapsed and parity_images) else None,
+                  "filter": ("broadcast from rank 0: %d bytes in %.3f ms (max over ranks), hash on every rank = rank 0's: %s"
+                             % (bcast["bytes"], bcast["seconds_max"] * 1e3, bcast["hash_min"] == bcast["hash_max"] == bcast["hash"]))
+                            if bcast is not None else "recomputed on every rank"}
         line = {
             "metric": "Mpixels/sec restored (FFT+Wiener+IFFT) at %dx%d fp32" % (S, S),
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -290,10 +384,13 @@ def main():
             "roofline": roofline,
             "check": {"images_done": images, "images_expected": int(tot[3]) * args.steps, "checksum": tot[1], "ranks_ok": int(tot[2]),
                       "ranks": world,
-                      "batch_vs_one_by_one": "%d images of rank 0 recomputed one at a time on one stream: bit-identical required" % len(sample)},
+                      "batch_vs_one_by_one": "all %d images of a step recomputed one at a time on one stream on every rank: bit-identical required%s"
+                                             % (B, "" if not differing else "; rank 0 DIFFERS at images %s" % differing[:16])},
         }
         if int(tot[2]) != world or images != int(tot[3]) * args.steps:
             rc = 3
+        if bcast is not None and not (bcast["hash_min"] == bcast["hash_max"] == bcast["hash"]):
+            rc = 5  # some rank holds a filter that is not rank 0's
         if world == 1 and not args.no_cpu_baseline:
             cs = args.cpu_size or min(S, 4096)
             line["cpu_baseline"], ref0 = cpu_baseline(cs)

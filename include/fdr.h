@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define FDR_VERSION 200 /* 0.2.0 */
+#define FDR_VERSION 300 /* 0.3.0 */
 
 /* status codes (reference: CHECK_CUDA prints and exit(1)s, fft/fft_gpu.cu:59-66; the C++ shim
  * reproduces that on any non-zero status) */
@@ -101,12 +101,35 @@ int fdr_psf_motion(int size, double angle_deg, float* out_host);
 /* device result into d_out (size*size floats), asynchronous on stream */
 int fdr_psf_motion_dev(int device, int size, double angle_deg, float* d_out, void* stream);
 
+/* -- the OpenCV call inside motionBlurKernel (utils.hpp:22): cv::warpAffine(src, dst, M, dsize) with its defaults
+ *    (INTER_LINEAR, BORDER_CONSTANT 0) on a single-channel float image, evaluated on the device in OpenCV's classic
+ *    fixed-point form (10-bit coordinates rounded to 1/32 pixel, 32 x 32 float weight table).
+ *    M: the 2 x 3 forward matrix (row-major) as cv::getRotationMatrix2D returns it; inverted in double as
+ *    cv::warpAffine does.  Host pointers; strides in elements.  fdr_psf_motion(size, angle) is this call applied to
+ *    the line kernel of utils.hpp:17-19 with the matrix of :20 (same bits).                                          */
+int fdr_warp_affine_f32(const float* src_host, int srows, int scols, int sstride, const double M[6],
+                        float* dst_host, int drows, int dcols, int dstride);
+
 /* -- PSF spectrum: pad top-left + forward 2-D FFT (fft/fft_serial.cpp:166-171,182;
  *    fft/fft_gpu.cu:340,356), kept in the plan together with K.                        */
 int fdr_set_psf(fdr_plan* plan, const float* psf_host, int prows, int pcols, int pstride, float K);
 int fdr_set_psf_dev(fdr_plan* plan, const float* d_psf, int prows, int pcols, int pstride, float K, void* stream);
 /* motionBlurKernel on the device straight into the plan (no host round trip) */
 int fdr_set_psf_motion(fdr_plan* plan, int size, double angle_deg, float K, void* stream);
+
+/* -- the prepared filter of a plan as an opaque block of bytes, for a caller that distributes ONE rank's PSF spectrum to the
+ *    others instead of recomputing it everywhere -- the role of the MPI_Bcast / MPI_Scatterv of the padded PSF in the
+ *    reference's MPI variant (fft/fft_mpi.cpp:334-378); in the batched mode a broadcast over RCCL (bench.py --bcast-filter).
+ *    The layout is private to the library (mode, flags and dimensions select it): a block exported from one plan may only be
+ *    imported into a plan created with the same (M, N, mode, flags) -- on any device.  `bytes` is the exact size.
+ *      fdr_plan_filter_bytes   size of the block (FDR_ERR_STATE on a tables-only plan)
+ *      fdr_plan_export_filter_dev  copy the plan's filter into d_dst (device memory of the plan's device), asynchronous on stream;
+ *                                  needs a PSF set on the plan
+ *      fdr_plan_import_filter_dev  copy d_src in as the plan's filter and take K with it: the plan then behaves as after
+ *                                  fdr_set_psf* with the exporting plan's PSF                                              */
+int fdr_plan_filter_bytes(const fdr_plan* plan, size_t* bytes);
+int fdr_plan_export_filter_dev(fdr_plan* plan, void* d_dst, size_t bytes, void* stream);
+int fdr_plan_import_filter_dev(fdr_plan* plan, const void* d_src, size_t bytes, float K, void* stream);
 
 /* -- the operator: fft_serial::wienerDeblur_myfft (fft/fft_serial.cpp:141-261) wrapped as
  *    serial.cpp:34-39 does (pad -> restore -> crop), one channel.  img rows x cols with row

@@ -17,14 +17,27 @@
 
 namespace cv {
 
-enum { CV_8U = 0, CV_32F = 5 };
+enum { CV_8U = 0, CV_32F = 5, CV_64F = 6 };
 constexpr int CV_MAKETYPE(int depth, int cn) { return depth + ((cn - 1) << 3); }
-enum { CV_8UC1 = 0, CV_8UC3 = 16, CV_32FC1 = 5, CV_32FC2 = 13, CV_32FC3 = 21 };
+enum { CV_8UC1 = 0, CV_8UC3 = 16, CV_32FC1 = 5, CV_32FC2 = 13, CV_32FC3 = 21, CV_64FC1 = 6 };
+// the enumerators of cv:: the reference's drivers and utils.hpp name (values as in OpenCV 4)
+enum { IMREAD_GRAYSCALE = 0, IMREAD_COLOR = 1 };
+enum { COLOR_BGR2Lab = 44, COLOR_Lab2BGR = 56 };
+enum { NORM_INF = 1, NORM_L1 = 2, NORM_L2 = 4, NORM_L2SQR = 5, NORM_MINMAX = 32 };
+enum { BORDER_CONSTANT = 0 };
+enum { INTER_NEAREST = 0, INTER_LINEAR = 1 };
 constexpr double CV_PI = 3.1415926535897932384626433832795;
 
-struct Size { int width = 0, height = 0; Size() {} Size(int w, int h) : width(w), height(h) {} };
+struct Size {
+    int width = 0, height = 0;
+    Size() {}
+    Size(int w, int h) : width(w), height(h) {}
+    bool operator==(const Size& o) const { return width == o.width && height == o.height; }
+    bool operator!=(const Size& o) const { return !(*this == o); }
+};
 struct Rect { int x = 0, y = 0, width = 0, height = 0; Rect() {} Rect(int x_, int y_, int w, int h) : x(x_), y(y_), width(w), height(h) {} };
 struct Point { int x = 0, y = 0; Point() {} Point(int x_, int y_) : x(x_), y(y_) {} };
+struct Point2f { float x = 0, y = 0; Point2f() {} Point2f(float x_, float y_) : x(x_), y(y_) {} Point2f(const Point& p) : x((float)p.x), y((float)p.y) {} };
 struct Vec2f { float v[2]; float& operator[](int i) { return v[i]; } const float& operator[](int i) const { return v[i]; } };
 struct Vec3f { float v[3]; float& operator[](int i) { return v[i]; } const float& operator[](int i) const { return v[i]; } };
 struct Vec3b { unsigned char v[3]; unsigned char& operator[](int i) { return v[i]; } const unsigned char& operator[](int i) const { return v[i]; } };
@@ -38,6 +51,7 @@ public:
 
     Mat() {}
     Mat(int r, int c, int type) { create(r, c, type); }
+    Mat(Size s, int type) { create(s.height, s.width, type); }
     static Mat zeros(int r, int c, int type) { Mat m(r, c, type); if (m.data) std::memset(m.data, 0, m.step * r); return m; }
     static Mat zeros(Size s, int type) { return zeros(s.height, s.width, type); }
 
@@ -50,7 +64,7 @@ public:
     int type() const { return type_; }
     int depth() const { return type_ & 7; }
     int channels() const { return (type_ >> 3) + 1; }
-    size_t elemSize() const { return (size_t)channels() * (depth() == CV_32F ? 4 : 1); }
+    size_t elemSize() const { return (size_t)channels() * (depth() == CV_64F ? 8 : depth() == CV_32F ? 4 : 1); }
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
     Size size() const { return Size(cols, rows); }
     size_t total() const { return (size_t)rows * cols; }

@@ -108,6 +108,10 @@ def _load():
     L.fdr_plan_dims.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
     L.fdr_psf_motion.argtypes = [ci, cd, vp]
     L.fdr_psf_motion_dev.argtypes = [ci, ci, cd, vp, vp]
+    L.fdr_warp_affine_f32.argtypes = [vp, ci, ci, ci, ctypes.POINTER(cd), vp, ci, ci, ci]
+    L.fdr_plan_filter_bytes.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t)]
+    L.fdr_plan_export_filter_dev.argtypes = [vp, vp, ctypes.c_size_t, vp]
+    L.fdr_plan_import_filter_dev.argtypes = [vp, vp, ctypes.c_size_t, cf, vp]
     L.fdr_set_psf.argtypes = [vp, vp, ci, ci, ci, cf]
     L.fdr_set_psf_dev.argtypes = [vp, vp, ci, ci, ci, cf, vp]
     L.fdr_set_psf_motion.argtypes = [vp, ci, cd, cf, vp]
@@ -136,7 +140,8 @@ def _load():
                  "fdr_fft2d_c2c", "fdr_fft2d_c2c_dev", "fdr_fft1d_c2c", "fdr_dft_naive_c2c", "fdr_synth_image_dev", "fdr_plan_profile", "fdr_plan_pass_times",
                  "fdr_optimal_dft_size", "fdr_plan_set_option", "fdr_plan_phase_times", "fdr_batch_run",
                  "fdr_slab_pad_dev", "fdr_slab_rows_fft_dev", "fdr_slab_pack_dev", "fdr_slab_transpose_dev", "fdr_slab_wiener_dev",
-                 "fdr_slab_real_dev", "fdr_slab_minmax_dev", "fdr_slab_normalize_dev"):
+                 "fdr_slab_real_dev", "fdr_slab_minmax_dev", "fdr_slab_normalize_dev", "fdr_warp_affine_f32",
+                 "fdr_plan_filter_bytes", "fdr_plan_export_filter_dev", "fdr_plan_import_filter_dev"):
         getattr(L, name).restype = ci
     return L
 
@@ -152,7 +157,8 @@ EXPORTED_SYMBOLS = (
     "fdr_fft2d_c2c_dev", "fdr_fft1d_c2c", "fdr_dft_naive_c2c", "fdr_synth_image_dev", "fdr_plan_profile",
     "fdr_plan_pass_times", "fdr_optimal_dft_size", "fdr_plan_set_option", "fdr_plan_phase_times", "fdr_batch_run",
     "fdr_slab_pad_dev", "fdr_slab_rows_fft_dev", "fdr_slab_pack_dev", "fdr_slab_transpose_dev", "fdr_slab_wiener_dev",
-    "fdr_slab_real_dev", "fdr_slab_minmax_dev", "fdr_slab_normalize_dev")
+    "fdr_slab_real_dev", "fdr_slab_minmax_dev", "fdr_slab_normalize_dev", "fdr_warp_affine_f32",
+    "fdr_plan_filter_bytes", "fdr_plan_export_filter_dev", "fdr_plan_import_filter_dev")
 
 
 def _check(rc):
@@ -192,6 +198,24 @@ def motionBlurKernel(size, angle):
     out = np.empty((int(size), int(size)), dtype=np.float32)
     _check(lib.fdr_psf_motion(int(size), float(angle), _ptr(out)))
     return out
+
+
+def warpAffine(src, M, dsize):
+    """cv::warpAffine(src, dst, M, dsize) with its defaults (bilinear, constant 0 border) on the device: src float32
+    [rows, cols], M the 2 x 3 forward matrix, dsize = (width, height) as cv::Size."""
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    m = (ctypes.c_double * 6)(*[float(v) for v in np.asarray(M, dtype=np.float64).reshape(6)])
+    out = np.empty((int(dsize[1]), int(dsize[0])), dtype=np.float32)
+    _check(lib.fdr_warp_affine_f32(_ptr(src), src.shape[0], src.shape[1], src.shape[1], m, _ptr(out), out.shape[0], out.shape[1], out.shape[1]))
+    return out
+
+
+def getRotationMatrix2D(center, angle, scale):
+    """cv::getRotationMatrix2D (utils.hpp:20): center = (x, y) rounded to float as cv::Point2f, angle in degrees."""
+    a = float(angle) * np.pi / 180.0
+    alpha, beta = np.cos(a) * scale, np.sin(a) * scale
+    cx, cy = float(np.float32(center[0])), float(np.float32(center[1]))
+    return np.array([[alpha, beta, (1 - alpha) * cx - beta * cy], [-beta, alpha, beta * cx + (1 - alpha) * cy]], dtype=np.float64)
 
 
 def autoPadToPowerOfTwo(src):
@@ -240,6 +264,18 @@ class Plan:
 
     def set_psf_motion(self, size, angle, K=0.01, stream=None):
         _check(lib.fdr_set_psf_motion(self._h, int(size), float(angle), ctypes.c_float(K), _stream(stream)))
+
+    # the prepared filter as an opaque block (one rank's PSF spectrum handed to the others: fft/fft_mpi.cpp:334-378)
+    def filter_bytes(self):
+        n = ctypes.c_size_t(0)
+        _check(lib.fdr_plan_filter_bytes(self._h, ctypes.byref(n)))
+        return int(n.value)
+
+    def export_filter_dev(self, d_dst, nbytes, stream=None):
+        _check(lib.fdr_plan_export_filter_dev(self._h, ctypes.c_void_p(int(d_dst)), int(nbytes), _stream(stream)))
+
+    def import_filter_dev(self, d_src, nbytes, K=0.01, stream=None):
+        _check(lib.fdr_plan_import_filter_dev(self._h, ctypes.c_void_p(int(d_src)), int(nbytes), ctypes.c_float(K), _stream(stream)))
 
     # operator
     def wiener(self, img, norm_area=NORM_PADDED):

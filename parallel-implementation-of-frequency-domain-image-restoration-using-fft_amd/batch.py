@@ -3,8 +3,9 @@ backend "nccl" = RCCL over xGMI, or "gloo" in CPU tests), independent images sha
 
 Images are independent units: there is no data-path collective.  The only
 collectives are (i) the barrier bracketing a timed region, (ii) a MAX all-reduce of the elapsed
-time and (iii) a SUM all-reduce of {images done, pixels done, checksum} as the end-of-batch
-consistency check.  Partitioning follows the reference's calculate_distribution
+time, (iii) a SUM all-reduce of {images done, pixels done, checksum} as the end-of-batch
+consistency check and, optionally (bench.py --bcast-filter), (iv) a broadcast of rank 0's prepared
+filter W in place of every rank recomputing it (setup, outside the timed region).  Partitioning follows the reference's calculate_distribution
 (fft/fft_mpi.cpp:89-100) applied to images instead of rows.
 """
 import time
@@ -62,6 +63,13 @@ class Comm:
         t = self._tensor([float(x)], torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
         return float(t.item())
+
+    def broadcast(self, tensor, src=0):
+        """dist.broadcast of a tensor in place (RCCL over xGMI under "nccl"); the data-carrying collective of the batched mode
+        (rank 0's prepared filter W to every rank: the MPI_Bcast / Scatterv of fft/fft_mpi.cpp:334-378).  Single process: no-op."""
+        if self.dist is not None:
+            self.dist.broadcast(tensor, src=src)
+        return tensor
 
     def gather_objects(self, obj):
         """list of every rank's picklable object on rank 0 (None elsewhere); plumbing for tests and result collection"""

@@ -195,11 +195,28 @@ struct ScopedPass {
     }
 };
 
+// folds the pending pairs whose end event has already completed (no waiting) into the sums; keeps the others
+void resolve_finished_phases(fdr_plan* p) {
+    size_t keep = 0;
+    for (auto& r : p->phase_pending) {
+        float ms = 0.f;
+        if (hipEventQuery(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            p->phase_ms[r.phase] += ms;
+            p->timer.pool.push_back(r.a); p->timer.pool.push_back(r.b);
+        } else {
+            p->phase_pending[keep++] = r;
+        }
+    }
+    p->phase_pending.resize(keep);
+}
+
 // One hipEvent pair on stream s around a phase of the reference's Profiler (fft/fft_gpu.cu:17-57); read back by
-// resolve_phases.  Bounded: beyond 1024 unread pairs further phases go unrecorded until fdr_plan_phase_times is called.
+// resolve_phases.  Bounded at 1024 unread pairs; from 768 on, pairs that have completed are folded in first (no waiting), so only
+// a caller with more than 1024 phases IN FLIGHT at once loses records.
 struct ScopedPhase {
     fdr_plan* p; hipStream_t s; fdr_plan::PhaseRec rec; bool on;
     ScopedPhase(fdr_plan* plan, int phase, hipStream_t st) : p(plan), s(st), on(false) {
+        if (p->phase_pending.size() >= 768) resolve_finished_phases(p);  // long host batches / many PSF rebuilds: fold what has completed
         if (p->phase_pending.size() < 1024) {
             rec.a = p->timer.get(); rec.b = p->timer.get(); rec.phase = phase;
             on = rec.a && rec.b;
@@ -764,6 +781,24 @@ int fdr_psf_motion(int size, double angle_deg, float* out_host) {
     return FDR_OK;
 }
 
+int fdr_warp_affine_f32(const float* src_host, int srows, int scols, int sstride, const double M[6], float* dst_host, int drows, int dcols,
+                        int dstride) {
+    if (!src_host || !dst_host || !M || srows <= 0 || scols <= 0 || sstride < scols || drows <= 0 || dcols <= 0 || dstride < dcols)
+        return fail(FDR_ERR_ARG, "fdr_warp_affine_f32: bad argument");
+    if (srows > 32767 || scols > 32767 || drows > 32767 || dcols > 32767)
+        return fail(FDR_ERR_ARG, "fdr_warp_affine_f32: image dimension above 32767 (cv::warpAffine's short coordinates)");
+    float *d_src = nullptr, *d_dst = nullptr;
+    const size_t sb = (size_t)scols * sizeof(float), db = (size_t)dcols * sizeof(float);
+    FDR_HIP(hipMalloc((void**)&d_src, sb * srows));
+    if (hipMalloc((void**)&d_dst, db * drows) != hipSuccess) { (void)hipFree(d_src); return fail(FDR_ERR_ALLOC, "fdr_warp_affine_f32: hipMalloc"); }
+    hipError_t e = hipMemcpy2D(d_src, sb, src_host, (size_t)sstride * sizeof(float), sb, srows, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_warp_affine(d_src, srows, scols, scols, M, d_dst, drows, dcols, dcols, nullptr);
+    if (e == hipSuccess) e = hipMemcpy2D(dst_host, (size_t)dstride * sizeof(float), d_dst, db, db, drows, hipMemcpyDeviceToHost);
+    (void)hipFree(d_src); (void)hipFree(d_dst);
+    FDR_HIP(e);
+    return FDR_OK;
+}
+
 int fdr_set_psf_dev(fdr_plan* p, const float* d_psf, int prows, int pcols, int pstride, float K, void* stream) {
     if (!p || !d_psf) return fail(FDR_ERR_ARG, "fdr_set_psf_dev: null argument");
     FDR_HIP(hipSetDevice(p->device));
@@ -795,6 +830,35 @@ int fdr_set_psf_motion(fdr_plan* p, int size, double angle_deg, float K, void* s
     if (rc != FDR_OK) return rc;
     FDR_HIP(launch_psf_motion(size, angle_deg, p->psf_dev, (hipStream_t)stream));
     return set_psf_dev_impl(p, p->psf_dev, size, size, size, K, (hipStream_t)stream);
+}
+
+int fdr_plan_filter_bytes(const fdr_plan* p, size_t* bytes) {
+    if (!p || !bytes) return fail(FDR_ERR_ARG, "fdr_plan_filter_bytes: null argument");
+    if (p->tables_only) return fail(FDR_ERR_STATE, "fdr_plan_filter_bytes: plan was created with FDR_FLAG_TABLES_ONLY");
+    *bytes = p->ws_elems * sizeof(float2);
+    return FDR_OK;
+}
+
+int fdr_plan_export_filter_dev(fdr_plan* p, void* d_dst, size_t bytes, void* stream) {
+    if (!p || !d_dst) return fail(FDR_ERR_ARG, "fdr_plan_export_filter_dev: null argument");
+    if (p->tables_only) return fail(FDR_ERR_STATE, "fdr_plan_export_filter_dev: plan was created with FDR_FLAG_TABLES_ONLY");
+    if (!p->have_psf) return fail(FDR_ERR_STATE, "fdr_plan_export_filter_dev: no PSF set on this plan");
+    if (bytes != p->ws_elems * sizeof(float2)) return fail(FDR_ERR_ARG, "fdr_plan_export_filter_dev: size differs from fdr_plan_filter_bytes");
+    FDR_HIP(hipSetDevice(p->device));
+    FDR_HIP(hipMemcpyAsync(d_dst, p->filt, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return FDR_OK;
+}
+
+int fdr_plan_import_filter_dev(fdr_plan* p, const void* d_src, size_t bytes, float K, void* stream) {
+    if (!p || !d_src) return fail(FDR_ERR_ARG, "fdr_plan_import_filter_dev: null argument");
+    if (p->tables_only) return fail(FDR_ERR_STATE, "fdr_plan_import_filter_dev: plan was created with FDR_FLAG_TABLES_ONLY");
+    if (bytes != p->ws_elems * sizeof(float2)) return fail(FDR_ERR_ARG, "fdr_plan_import_filter_dev: size differs from fdr_plan_filter_bytes");
+    FDR_HIP(hipSetDevice(p->device));
+    ScopedPhase phase(p, FDR_PHASE_PRE, (hipStream_t)stream);
+    FDR_HIP(hipMemcpyAsync(p->filt, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    p->K = K;
+    p->have_psf = true;
+    return FDR_OK;
 }
 
 int fdr_wiener_f32_dev(fdr_plan* p, const float* d_img, int rows, int cols, int stride, float* d_out, int out_stride,
@@ -1324,8 +1388,12 @@ int batch_worker_run(const fdr_batch_desc* d, BatchWorker* w, std::chrono::stead
         if (w->count == 0) return FDR_OK;
         int r = fdr_plan_create(w->device, d->M, d->N, d->mode, d->flags, &plan);
         if (r != FDR_OK) return r;
+        // the worker's stream exists BEFORE the PSF spectrum is queued, and the generated PSF is prepared ON it: the batches
+        // below run on this (non-blocking) stream and its forks, which never synchronise with the null stream by themselves
+        // (fdr_set_psf with a host PSF synchronises before it returns)
+        FDR_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         if (d->psf_host) r = fdr_set_psf(plan, d->psf_host, d->psf_rows, d->psf_cols, d->psf_stride, d->K);
-        else r = fdr_set_psf_motion(plan, d->psf_size, d->psf_angle_deg, d->K, nullptr);
+        else r = fdr_set_psf_motion(plan, d->psf_size, d->psf_angle_deg, d->K, stream);
         if (r != FDR_OK) return r;
         if (d->imgs_host) {  // host images: the pipelined host batch over this worker's shard
             const auto t0 = std::chrono::steady_clock::now();
@@ -1352,7 +1420,6 @@ int batch_worker_run(const fdr_batch_desc* d, BatchWorker* w, std::chrono::stead
         r = fdr_plan_set_batching(plan, ns, d->mode == FDR_MODE_FAST ? gr : 1);
         if (r != FDR_OK) return r;
         const size_t P = (size_t)d->rows * d->cols, total = P * (size_t)w->count;
-        FDR_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         FDR_HIP(hipMalloc((void**)&d_in, total * sizeof(float)));
         FDR_HIP(hipMalloc((void**)&d_out, total * sizeof(float)));
         FDR_HIP(hipMalloc((void**)&d_part, 1024 * sizeof(double)));

@@ -60,17 +60,15 @@ hipError_t launch_simple_rows(float2* data, int rows, int L, int logl, const flo
     int threads = L / 2;
     if (threads < 64) threads = 64;
     if (threads > 1024) threads = 1024;
-    if (smem > 48 * 1024) {  // opt in once to a 64 KiB dynamic LDS row (the reference never does)
-        static bool opted = false;
-        if (!opted) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&simple_rows_kernel<PolicyParity>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&simple_rows_kernel<PolicyFast>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            if (e != hipSuccess) return e;
-            opted = true;
-        }
+    if (smem > 48 * 1024) {
+        // opt in to a 64 KiB dynamic LDS row (the reference never does).  A function attribute belongs to the
+        // CURRENT device's copy of the code object, and fdr_batch_run drives one host thread per device: set it on every such
+        // launch (a host-side table write, no device work) instead of remembering a process-wide "done" flag
+        hipError_t e = mode == 0 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&simple_rows_kernel<PolicyParity>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)
+                                 : hipFuncSetAttribute(reinterpret_cast<const void*>(&simple_rows_kernel<PolicyFast>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e != hipSuccess) return e;
     }
     if (mode == 0)
         hipLaunchKernelGGL(simple_rows_kernel<PolicyParity>, dim3(rows), dim3(threads), smem, s, data, rows, L, logl, tw);
@@ -343,6 +341,57 @@ hipError_t launch_psf_motion(int size, double angle_deg, float* d_out, hipStream
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(psf_motion_kernel, dim3(blocks), dim3(256), 0, s, size, map, d_out);
+    return hipGetLastError();
+}
+
+// ---- cv::warpAffine(src, dst, M, dsize) with its defaults (INTER_LINEAR, BORDER_CONSTANT 0) for a single-channel float
+// image, as utils.hpp:22 calls it: the same fixed-point replay as psf_motion_kernel, the source read from memory.
+// `map` is the INVERTED matrix (dst -> src), prepared on the host in double as cv::warpAffine does.
+__device__ __forceinline__ int sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+__global__ void warp_affine_kernel(const float* __restrict__ src, int srows, int scols, int sstride, PsfMap map, float* __restrict__ dst,
+                                   int drows, int dcols, int dstride) {
+    const long long total = (long long)drows * dcols;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(idx / dcols), x = (int)(idx % dcols);
+        const int X0 = cv_round_dev((map.m[1] * y + map.m[2]) * 1024.0) + 16;
+        const int Y0 = cv_round_dev((map.m[4] * y + map.m[5]) * 1024.0) + 16;
+        const int adelta = cv_round_dev(map.m[0] * x * 1024.0), bdelta = cv_round_dev(map.m[3] * x * 1024.0);
+        const int X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+        const int sx = sat_short(X >> 5), sy = sat_short(Y >> 5), ax = X & 31, ay = Y & 31;
+        const float fx = ax * (1.f / 32.f), fy = ay * (1.f / 32.f);
+        const float vx0 = 1.f - fx, vx1 = fx, vy0 = 1.f - fy, vy1 = fy;
+        const float w0 = vy0 * vx0, w1 = vy0 * vx1, w2 = vy1 * vx0, w3 = vy1 * vx1;
+        const bool x0in = sx >= 0 && sx < scols, x1in = sx + 1 >= 0 && sx + 1 < scols;
+        const bool y0in = sy >= 0 && sy < srows, y1in = sy + 1 >= 0 && sy + 1 < srows;
+        const float s00 = (y0in && x0in) ? src[(size_t)sy * sstride + sx] : 0.f;
+        const float s01 = (y0in && x1in) ? src[(size_t)sy * sstride + sx + 1] : 0.f;
+        const float s10 = (y1in && x0in) ? src[(size_t)(sy + 1) * sstride + sx] : 0.f;
+        const float s11 = (y1in && x1in) ? src[(size_t)(sy + 1) * sstride + sx + 1] : 0.f;
+        const float t0 = s00 * w0, t1 = s01 * w1, t2 = s10 * w2, t3 = s11 * w3;
+        float acc = t0 + t1;
+        acc = acc + t2;
+        acc = acc + t3;
+        dst[(size_t)y * dstride + x] = acc;
+    }
+}
+
+hipError_t launch_warp_affine(const float* src, int srows, int scols, int sstride, const double fwd[6], float* dst, int drows, int dcols,
+                              int dstride, hipStream_t s) {
+    if (drows <= 0 || dcols <= 0) return hipSuccess;
+    double M[6];
+    for (int i = 0; i < 6; ++i) M[i] = fwd[i];
+    double D = M[0] * M[4] - M[1] * M[3];  // invertAffineTransform inside cv::warpAffine
+    D = D != 0 ? 1. / D : 0;
+    const double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11; M[1] *= -D; M[3] *= -D; M[4] = A22;
+    const double b1 = -M[0] * M[2] - M[1] * M[5];
+    const double b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+    PsfMap map;
+    for (int i = 0; i < 6; ++i) map.m[i] = M[i];
+    long long blocks = ((long long)drows * dcols + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(warp_affine_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, srows, scols, sstride, map, dst, drows, dcols, dstride);
     return hipGetLastError();
 }
 

@@ -123,6 +123,9 @@ int cols_minmax_partials(int logm, int N);
 hipError_t launch_normalize(const float* raw, int N, const float2* mm_part, int n_part, const float* mm, float* out,
                             int rows, int cols, int out_stride, hipStream_t s, const NormBatch* batch = nullptr);
 hipError_t launch_psf_motion(int size, double angle_deg, float* d_out, hipStream_t s);
+// cv::warpAffine defaults (bilinear, constant 0 border) on a single-channel float image; fwd = the 2 x 3 matrix as cv::warpAffine takes it
+hipError_t launch_warp_affine(const float* src, int srows, int scols, int sstride, const double fwd[6], float* dst, int drows, int dcols,
+                              int dstride, hipStream_t s);
 // slab mode (single image over several GPUs): column blocks of a row slab packed for the all-to-all, dense transposes
 // of 4- or 8-byte elements, real part, min/max partials of a real plane
 hipError_t launch_slab_pack(const void* src, int rows, int ld, int parts, const int* counts, int elem_size, void* dst, hipStream_t s);

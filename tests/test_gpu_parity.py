@@ -325,6 +325,21 @@ def test_phase_times_and_batch_run(fdr, oracle):
         for i in range(6):
             ref_sum += float(q.wiener(oracle.synth_image(0x5EED0005, i * 65536, 65536).reshape(256, 256)).astype(np.float64).sum())
     assert abs(sum(st2["checksum"]) - ref_sum) < 1e-3, (sum(st2["checksum"]), ref_sum)
+    # no warm-up and a single timed pass: the very first batch reads the filter the (asynchronous, generated-on-device)
+    # PSF preparation writes -- both are ordered on the worker's own stream
+    st3, _ = fdr.batch_run([0, 0, 0], 256, 256, 6, mode=fdr.MODE_FAST, psf_size=15, psf_angle=30.0, seed=0x5EED0005, steps=1, warmup=0)
+    assert st3["images_done"] == 6 and abs(sum(st3["checksum"]) - ref_sum) < 1e-3, (sum(st3["checksum"]), ref_sum)
+    # two host threads on the reference-shaped path at 8192 points: the 64 KiB dynamic-LDS opt-in of its row kernel is made
+    # per launch on the launching thread's device (it used to hide behind a process-wide flag set by the first thread)
+    st4, _ = fdr.batch_run([0, 0], 64, 8192, 2, mode=fdr.MODE_PARITY, flags=fdr.FLAG_SIMPLE_PATH, psf_size=15, psf_angle=30.0,
+                           seed=0x5EED0006, steps=1, warmup=0, nstreams=1, group=1)
+    assert st4["status"] == [0, 0] and st4["images_done"] == 2
+    ref4 = 0.0
+    with fdr.Plan(64, 8192, fdr.MODE_PARITY) as q:
+        q.set_psf(fdr.motionBlurKernel(15, 30.0), 0.01)
+        for i in range(2):
+            ref4 += float(q.wiener(oracle.synth_image(0x5EED0006, i * 64 * 8192, 64 * 8192).reshape(64, 8192)).astype(np.float64).sum())
+    assert abs(sum(st4["checksum"]) - ref4) < 1e-3, (sum(st4["checksum"]), ref4)
     with pytest.raises(fdr.FdrError):
         fdr.batch_run([0, 99], 128, 256, 2, rows=100, cols=200, psf=psf, imgs=imgs[:2])  # device ordinal out of range
     with pytest.raises(fdr.FdrError):
@@ -632,6 +647,68 @@ def test_grouped_batch_at_config5_size_against_oracle(fdr, oracle, S, B):
         assert mx <= TOL and rel <= TOL, (i, mx, rel)
 
 
+def test_one_gpu_shard_of_config5_every_image(fdr, oracle):
+    """One GPU's shard of BASELINE config 5 at G = 8 -- 64 x 2048^2 (seed 0x5EED0005) -- through fdr_wiener_batch_f32_dev
+    with bench.py's batching for this size (2 streams x 4 images per launch), three times over: EVERY image of every pass
+    must carry the bits of the one-image-at-a-time path (compared on the device), must span [0, 1], and images 0, 21, 42
+    and 63 must be within 1e-4 of the CPU oracle.  (Round 2's LDS race lived in the images nobody compared.)"""
+    import torch
+    S, B = 2048, 64
+    P = S * S
+    psf = oracle.motion_blur_kernel(50, 30.0)
+    d_in = torch.empty((B, S, S), dtype=torch.float32, device="cuda")
+    fdr.synth_image_dev(d_in.data_ptr(), B * P, 0x5EED0005)
+    d_grp = torch.zeros_like(d_in)
+    d_one = torch.zeros_like(d_in)
+    s = torch.cuda.current_stream().cuda_stream
+    with fdr.Plan(S, S, fdr.MODE_FAST) as p:
+        p.set_psf(psf, 0.01)
+        for i in range(B):
+            p.wiener_dev(d_in[i].data_ptr(), S, S, S, d_one[i].data_ptr(), S, stream=s)
+        p.set_batching(2, 4)
+        for rep in range(3):
+            d_grp.zero_()
+            p.wiener_batch_dev(d_in.data_ptr(), P, B, S, S, S, d_grp.data_ptr(), P, S, stream=s)
+            torch.cuda.synchronize()
+            bad = [i for i in range(B) if not bool(torch.equal(d_grp[i], d_one[i]))]
+            assert not bad, ("pass %d: images that differ from the one-by-one path" % rep, bad)
+    assert bool(((d_grp.amin(dim=(1, 2)) == 0.0) & (d_grp.amax(dim=(1, 2)) > 1.0 - 1e-6)).all().item())
+    for i in (0, 21, 42, 63):
+        img = oracle.synth_image(0x5EED0005, i * P, P).reshape(S, S)
+        ref = oracle.serial_channel(img, psf, 0.01)
+        got = d_grp[i].cpu().numpy()
+        mx = float(np.abs(got - ref).max())
+        rel = float(np.linalg.norm((got - ref).astype(np.float64)) / np.linalg.norm(ref.astype(np.float64)))
+        assert mx <= TOL and rel <= TOL, (i, mx, rel)
+
+
+def test_filter_block_export_import_between_plans(fdr, oracle):
+    """fdr_plan_export_filter_dev / fdr_plan_import_filter_dev (what bench.py --bcast-filter moves with dist.broadcast):
+    a plan that IMPORTS another plan's filter block restores the same bits as the plan that built it from the PSF, in both
+    modes; size and state errors are reported."""
+    import torch
+    psf = oracle.motion_blur_kernel(15, 30.0)
+    img = _image(oracle, 200, 300, 0x1234)
+    for mode in (fdr.MODE_FAST, fdr.MODE_PARITY):
+        with fdr.Plan(256, 512, mode) as a, fdr.Plan(256, 512, mode) as b:
+            a.set_psf(psf, 0.01)
+            n = a.filter_bytes()
+            assert n == b.filter_bytes() and n > 0
+            blk = torch.empty(n, dtype=torch.uint8, device="cuda")
+            with pytest.raises(fdr.FdrError):
+                b.export_filter_dev(blk.data_ptr(), n)  # no PSF on b yet
+            with pytest.raises(fdr.FdrError):
+                b.wiener(img)
+            a.export_filter_dev(blk.data_ptr(), n)
+            with pytest.raises(fdr.FdrError):
+                b.import_filter_dev(blk.data_ptr(), n - 8, 0.01)
+            b.import_filter_dev(blk.data_ptr(), n, 0.01)
+            torch.cuda.synchronize()
+            _assert_same(b.wiener(img), a.wiener(img), "imported filter block, mode %d" % mode)
+            if mode == fdr.MODE_PARITY:
+                _assert_same(b.wiener(img), oracle.serial_channel(img, psf, 0.01), "imported filter block vs oracle")
+
+
 def test_cat_picture_through_both_clis(fdr, oracle, tmp_path):
     """BASELINE config 1's named input: `./serial input/cat_blurred.png 50 30` (782 x 1920 -> 1024 x 2048).  This is the
     picture whose minimum lies in the PADDING (normalising over the cropped area instead would move the
@@ -748,6 +825,68 @@ def test_serial_style_cli_gives_the_serial_pixels(fdr, oracle, tmp_path):
     assert subprocess.run([_os.path.join(root, "tools", "cli", "serial")], capture_output=True).returncode == 255
     bad = subprocess.run([_os.path.join(root, "tools", "cli", "serial"), "/nonexistent.png", "40", "45"], capture_output=True, text=True)
     assert bad.returncode == 255 and "Cannot read image" in bad.stdout
+
+
+def test_reference_drivers_built_unchanged_run_on_the_drop_in_surface(fdr, oracle, tmp_path):
+    """oracle/_ref/{serial,gpu}_{swap,bind}: the reference's OWN serial.cpp / gpu.cpp, compiled unchanged in the build
+    container (oracle/Makefile `ref_mains`; the GPU box has no reference checkout and uses the built files) against
+    include/ -- `swap`: with include/utils.hpp + include/fft/fft.hpp; `bind`: with the reference's utils.hpp + fft/fft.hpp and
+    the binding file tools/cli/fft_hip.cpp, so motionBlurKernel is the reference's code over cv::warpAffine of
+    include/fdr_cv.hpp (the device kernel).  The picture serial.cpp hands to imshow (written to FDR_IMSHOW_DIR by the
+    shim) must equal what tools/cli/serial writes for the same command line within 1 at 8 bit (host Lab formulae against
+    the device epilogue; the restored planes underneath are the oracle-identical parity-mode ones)."""
+    import subprocess
+    from PIL import Image
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    ref_dir = _os.path.join(root, "oracle", "_ref")
+    if not all(_os.path.exists(_os.path.join(ref_dir, n)) for n in ("serial_swap", "serial_bind", "gpu_swap", "gpu_bind")):
+        pytest.skip("oracle/_ref/* not built (needs /root/reference at build time)")
+    subprocess.check_call(["make", "-C", _os.path.join(root, "tools", "cli"), "-s", "serial"])
+    png = _os.path.join(root, "tests", "golden", "car_blurred.png")
+    ours = str(tmp_path / "ours.png")
+    r = subprocess.run([_os.path.join(root, "tools", "cli", "serial"), png, "40", "45", "--out", ours], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    want = np.asarray(Image.open(ours)).astype(np.int16)
+    for exe in ("serial_swap", "serial_bind"):
+        d = tmp_path / exe
+        d.mkdir()
+        env = dict(_os.environ, FDR_IMSHOW_DIR=str(d))
+        r = subprocess.run([_os.path.join(ref_dir, exe), png, "40", "45"], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, (exe, r.stdout, r.stderr)
+        assert "Deblurring 3 channels took(serial):" in r.stdout and "Total program time:" in r.stdout, r.stdout
+        if exe == "serial_swap":  # include/fft/fft.hpp prints the accumulated phase block of fft/fft_serial.cpp:249-258
+            assert r.stdout.count("=== Accumulated Time ===") == 1
+        got = np.asarray(Image.open(str(d / "Deblurred_Color_Image.png"))).astype(np.int16)
+        assert got.shape == want.shape
+        diff = np.abs(got - want)
+        assert diff.max() <= 1 and np.count_nonzero(diff) < 0.02 * diff.size, (exe, int(diff.max()), int(np.count_nonzero(diff)))
+        assert subprocess.run([_os.path.join(ref_dir, exe)], capture_output=True).returncode == 255          # serial.cpp:12-15
+        bad = subprocess.run([_os.path.join(ref_dir, exe), "/nonexistent.png", "40", "45"], capture_output=True, text=True)
+        assert bad.returncode == 255 and "Cannot read image" in bad.stdout                                 # serial.cpp:23
+    for exe in ("gpu_swap", "gpu_bind"):
+        r = subprocess.run([_os.path.join(ref_dir, exe), png, "40", "45"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (exe, r.stdout, r.stderr)
+        for line in ("Deblurring 3 channels took(serial):", "Deblurring 3 channels took(gpu[optimize]):", "Deblurring 3 channels took(gpu):"):
+            assert line in r.stdout, (exe, line, r.stdout)                                                  # gpu.cpp:91,104,112
+        assert r.stdout.count("[Speedup]") == 2
+        assert subprocess.run([_os.path.join(ref_dir, exe)], capture_output=True).returncode == 255
+
+
+def test_warp_affine_on_device_is_the_psf_generator(fdr, oracle):
+    """cv::warpAffine of the drop-in surface (fdr_warp_affine_f32): applied to the line kernel of utils.hpp:17-19 with
+    cv::getRotationMatrix2D's matrix (:20) it must give the bits of motionBlurKernel / the oracle; identity and integer
+    translation are exact copies with a zero border."""
+    for size, angle in ((50, 30.0), (40, 45.0), (15, 10.0), (7, 90.0), (64, 123.4)):
+        kernel = np.zeros((size, size), np.float32)
+        kernel[size // 2, :] = np.float32(1.0 / size)
+        M = fdr.getRotationMatrix2D((size // 2, size // 2), angle, 1.0)
+        _assert_same(fdr.warpAffine(kernel, M, (size, size)), oracle.motion_blur_kernel(size, angle), "warpAffine(line kernel) %d/%g" % (size, angle))
+    img = _image(oracle, 37, 53, 0x77)
+    _assert_same(fdr.warpAffine(img, [[1, 0, 0], [0, 1, 0]], (53, 37)), img, "identity warp")
+    sh = fdr.warpAffine(img, [[1, 0, 5], [0, 1, 3]], (60, 45))  # dst(x, y) = src(x - 5, y - 3)
+    want = np.zeros((45, 60), np.float32)
+    want[3:40, 5:58] = img
+    _assert_same(sh, want, "integer translation with zero border")
 
 
 def test_cpp_shim_surface(fdr, oracle, tmp_path):

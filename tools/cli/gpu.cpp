@@ -96,6 +96,10 @@ int main(int argc, char** argv) {
     auto t_end = high_resolution_clock::now();
     const double serial_time = getElapsedMs(t_start, t_end);
     cout << "Deblurring 3 channels took(serial): " << serial_time << " ms\n";
+    // (what that leg is HERE: fft_serial:: on the GPU in the parity mode, one plan + PSF spectrum per channel, run cold --
+    // this binary has no CPU path, so the two [Speedup] ratios below compare GPU parity-mode-cold with GPU fast mode, not a
+    // CPU with a GPU as gpu.cpp:105,113 of the reference do)
+    cout << "[Note] serial leg = fft_serial:: names on the GPU (parity mode, cold); [Speedup] = that leg / the GPU entry point\n";
 
     fft_gpu::wienerDeblur_RGB_optimized(channels, psf, K);  // warm-up, as gpu.cpp:96 (restores in place)
 
