@@ -1395,6 +1395,111 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
     if (active) tile_store<Core>(data, loff, v);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pass B' for ONE small image (the single-image call of BASELINE config 2: M <= 2048).  The tile kernels above give a
+// 4-column tile to one thread group (64 threads at 1024 points): with a single image in flight that is 128 one-wave
+// workgroups, each running eight 1024-point transforms back to back on one SIMD -- 10 us of dependent VALU and memory
+// latency on a chip that is 95 % idle (measured 14.2 us event-timed at 1024^2, 9.8 with the transforms compiled out).
+// Here the four columns of a panel go to four thread groups of one workgroup (B = 1 transform per group, same FftCore
+// step plan and policy as the tile kernel of that length, so the bits are the same), the filter is requested together with
+// the spectrum (16 or 8 values per lane leave the registers for it), and nothing is staged.  The thread groups are
+// INTERLEAVED over the lanes -- column = lane & 3, logical thread = lane >> 2 -- so that for every (u, q) slot the 64 lanes
+// of a wave touch 16 rows x 4 columns = 512 contiguous bytes: dense 8-byte-per-lane accesses (with column = lane / T each
+// wave read 8 of every 32 bytes, which held the 2048-row case at the tile kernel's time).  The groups' exchange buffers are
+// 16 dwords apart modulo the 64 banks, so the four 8-lane runs of a half wave fall on disjoint banks in the contiguous
+// phases of an exchange.
+// ---------------------------------------------------------------------------------------------
+template <int LOGM>
+struct PanelSplitGeom {
+    static constexpr int LOGV = LOGM >= 10 ? 4 : 3;  // as the tile kernels: radix-16 steps from 1024 points on, radix-8 below
+    using St = Steps<LOGM, LOGV>;
+    static constexpr int T = St::T;
+    static constexpr int THREADS = 4 * T;
+};
+
+template <int LOGM>
+__global__ __launch_bounds__(PanelSplitGeom<LOGM>::THREADS) void fft_cols_panel_split_kernel(
+    float2* __restrict__ data, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const unsigned pstride, const int packed0) {
+    using Geo = PanelSplitGeom<LOGM>;
+    using St = typename Geo::St;
+    constexpr int M = St::L, V = St::V;
+    using Core = FftCore<LOGM, 1, 2, PolicyFast, Geo::LOGV, false>;
+    constexpr int GRP = 2 * St::BUF + ((24 - (2 * St::BUF) % 32) & 31);  // float2 elements per group, = 24 (mod 32): 48 dwords (mod 64)
+    static_assert(GRP % 32 == 24, "group stride");
+    __shared__ float2 lds[4 * GRP];
+    const int c = (int)(threadIdx.x & 3);   // column of the panel
+    const int tid = (int)(threadIdx.x >> 2);  // logical thread of that column's transform
+    float2* grp_lds = lds + c * GRP;
+    float2* __restrict__ col = data + (size_t)blockIdx.x * pstride + c;           // element (m, c) of the panel at col[4 m]
+    const float2* __restrict__ wcol = filt + (size_t)blockIdx.x * pstride + c;
+
+    typename Core::Bases bases;
+    Core::init_bases(bases, tw_fwd, tid);
+
+    float2 v[1][V], w[V];
+#pragma unroll
+    for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+        for (int q = 0; q < Core::RHO0; ++q) v[0][u * Core::RHO0 + q] = col[(size_t)Core::in_index(tid, u, q) * 4];
+#pragma unroll
+    for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+        for (int q = 0; q < Core::RHOL; ++q) w[u * Core::RHOL + q] = wcol[(size_t)Core::out_index(tid, u, q) * 4];
+
+    Core::template run<0, false>(v, grp_lds, tw_fwd, bases, tid);
+
+    constexpr int SEQ = Core::SLOTS;
+    const bool packed_tile = packed0 && blockIdx.x == 0;  // uniform per workgroup
+    if (packed_tile) {  // column 0 of panel 0 carries DC + i Nyquist (see packed_column_filter): finished by its own thread group
+        // (the buffer of slot SEQ is free: its last readers passed the barrier of the exchange after it)
+        float2* bufc = grp_lds + (SEQ & 1) * St::BUF;
+        FDR_JITTER(4031);
+        if (c == 0) {
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) bufc[Core::out_index(tid, u, q)] = v[0][u * Core::RHOL + q];
+        }
+        __syncthreads();
+        FDR_JITTER(4032);
+        if (c == 0) {
+#pragma unroll
+            for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int s = u * Core::RHOL + q;
+                    const int k = Core::out_index(tid, u, q);
+                    const int km = (M - k) & (M - 1);
+                    const float2 cc = v[0][s], cm = bufc[km], sl = w[s], sm = wcol[(size_t)km * 4];
+                    const float2 f0 = make_float2(0.5f * (cc.x + cm.x), 0.5f * (cc.y - cm.y));
+                    const float2 fn = make_float2(0.5f * (cc.y + cm.y), 0.5f * (cm.x - cc.x));
+                    float2 a0, an;
+                    if (k == 0 || k == M / 2) { a0 = make_float2(sl.x, 0.f); an = make_float2(sl.y, 0.f); }
+                    else if (k < M / 2) { a0 = sl; an = sm; }
+                    else { a0 = make_float2(sm.x, -sm.y); an = make_float2(sl.x, -sl.y); }
+                    const float2 z0 = cmul_fma(f0, a0), zn = cmul_fma(fn, an);
+                    v[0][s] = make_float2(z0.x - zn.y, z0.y + zn.x);
+                    w[s] = make_float2(1.f, 0.f);
+                }
+        }
+        __syncthreads();  // bufc was read: the inverse transform's first exchange writes it
+    }
+#pragma unroll
+    for (int s = 0; s < V; ++s) v[0][s] = cmul_fma(v[0][s], w[s]);
+
+    Core::permute_out_to_in(v);
+    Core::template run<SEQ, true>(v, grp_lds, tw_fwd, bases, tid);
+
+#pragma unroll
+    for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+        for (int q = 0; q < Core::RHOL; ++q) col[(size_t)Core::out_index(tid, u, q) * 4] = v[0][u * Core::RHOL + q];
+}
+
+#ifndef FDR_COLS_SPLIT
+#define FDR_COLS_SPLIT 1  // single images with 256 .. 2048 rows: one thread group per COLUMN (A/B builds: 0)
+#endif
+
 template <int LOGM>
 static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const float2* tw, hipStream_t s) {
     using Geo = PanelGeom<LOGM>;
@@ -1408,6 +1513,13 @@ static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const floa
         PanelBatch pb = a.batch;
         if (pb.nimg <= 0) { pb.nimg = 1; pb.data[0] = a.data; }
         for (int k = pb.nimg; k < kMaxGroup; ++k) pb.data[k] = pb.data[0];
+        if constexpr (FDR_COLS_SPLIT && LOGM >= 8 && LOGM <= 11) {
+            if (pb.nimg == 1) {  // a single small image: latency, not bandwidth (see fft_cols_panel_split_kernel)
+                hipLaunchKernelGGL((fft_cols_panel_split_kernel<LOGM>), dim3(npanels), dim3(PanelSplitGeom<LOGM>::THREADS), 0, s, pb.data[0], a.filt, tw,
+                                   (unsigned)ps, a.packed0);
+                return hipGetLastError();
+            }
+        }
         if constexpr (LOGM >= 10) {  // 16 values per thread: one workgroup per tile, grid (tiles, images)
             using G16 = Panel16Geom<LOGM>;
             const int nt16 = (npanels + G16::G - 1) / G16::G;

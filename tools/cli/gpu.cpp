@@ -99,7 +99,7 @@ int main(int argc, char** argv) {
     // (what that leg is HERE: fft_serial:: on the GPU in the parity mode, one plan + PSF spectrum per channel, run cold --
     // this binary has no CPU path, so the two [Speedup] ratios below compare GPU parity-mode-cold with GPU fast mode, not a
     // CPU with a GPU as gpu.cpp:105,113 of the reference do)
-    cout << "[Note] serial leg = fft_serial:: names on the GPU (parity mode, cold); [Speedup] = that leg / the GPU entry point\n";
+    cout << "[Note] serial leg = fft_serial:: names on the GPU (parity mode, cold); the speed-up lines divide that leg by a GPU entry point\n";
 
     fft_gpu::wienerDeblur_RGB_optimized(channels, psf, K);  // warm-up, as gpu.cpp:96 (restores in place)
 
