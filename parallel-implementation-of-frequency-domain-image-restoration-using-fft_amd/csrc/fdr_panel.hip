@@ -1254,6 +1254,9 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::PIPE_WAV
 #ifndef FDR_COLS12_PACKED
 #define FDR_COLS12_PACKED 1
 #endif
+#ifndef FDR_PARK_BASES
+#define FDR_PARK_BASES 1  // 8192-point column pass: twiddle bases parked in LDS across the filter phase (A/B builds: 0)
+#endif
 
 template <int LOGM>
 struct Panel16Geom {
@@ -1295,9 +1298,22 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
 
     typename Core::Bases bases;
     Core::init_bases(bases, tw_fwd, tid);
+    // 8192 points: the tile fills 128 of the 256 registers a lane has and the filter phase needs the rest, so the hoisted
+    // twiddle bases (one float2 per radix-16 step) did not survive it -- hipcc spilled them in the forward transform and
+    // reloaded them from scratch in the inverse (3 x 8 bytes per lane: 28 bytes of scratch, ~50 MB of HBM traffic per
+    // two-image launch, and three exposed memory round trips).  They are parked in the 12 KB of LDS the exchange buffers
+    // leave instead and picked up again for the inverse: an LDS read where a scratch load was.
+    constexpr bool kParkBases = (LOGM == 13) && FDR_PARK_BASES;
+    __shared__ float2 parked[kParkBases ? (St::S - 1) * T : 1];
+    if constexpr (kParkBases) {
+#pragma unroll
+        for (int j = 1; j < St::S; ++j) parked[(j - 1) * T + tid] = bases.b[j][0];  // (the logical index: one slot per thread)
+    }
 
     // (Delaying the workgroup that landed in the odd wave slots by half a load phase, so that the two workgroups of
-    // a CU alternate between memory and LDS phases, was measured: no gain up to 5 us of delay, slower beyond.)
+    // a CU alternate between memory and LDS phases, was measured: no gain up to 5 us of delay, slower beyond.  Round 3, the
+    // same across CUs: every other TILE's first-round workgroup started 7 .. 40 us late -- 4096^2 35.1 / 34.0 / 34.4 / 36.5 us,
+    // 8192^2 192.7 / 186.3 / 193.9 / 201.5 us per image at 0 / 7 / 14 / 20 us: the CUs are not in lockstep to begin with.)
     float2 v[4][V];
     tile_load<Core, false>(data, loff, 1u, v);
     Core::template run<0, false>(v, grp_lds, tw_fwd, bases, tid);
@@ -1390,7 +1406,14 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
         int ti = tid;
         asm volatile("" : "+v"(ti));
         Core::permute_out_to_in(v);  // (a renaming of registers when the first and the last radix differ)
-        Core::template run<SEQ, true>(v, grp_lds, tw_fwd, bases, ti);
+        if constexpr (kParkBases) {
+            typename Core::Bases inv_bases;
+#pragma unroll
+            for (int j = 1; j < St::S; ++j) inv_bases.b[j][0] = parked[(j - 1) * T + ti];
+            Core::template run<SEQ, true>(v, grp_lds, tw_fwd, inv_bases, ti);
+        } else {
+            Core::template run<SEQ, true>(v, grp_lds, tw_fwd, bases, ti);
+        }
     }
     if (active) tile_store<Core>(data, loff, v);
 }
