@@ -38,11 +38,40 @@ namespace fdr {
 //   inverse : Z = Y_a + i Y_b  ->  z = IFFT(Z);  row a = Re z, row b = Im z   (no fix-up at all)
 // A 4-row group therefore costs 2 complex transforms instead of 4.
 // ---------------------------------------------------------------------------------------------
+#ifndef FDR_SWAP0
+#define FDR_SWAP0 1  // v_permlane32_swap exchange behind a radix-2 first step (8192-point transforms on the 16-value core)
+#endif
+// The one-group row kernels (a workgroup lives for one 4-row group) hold 8 values per thread (radix-8 steps) -- except for
+// rows of FDR_ROWS_ONE_V16_MIN .. FDR_ROWS_ONE_V16_MAX points (log2), which take 16 (radix-16 steps: two LDS exchanges
+// instead of three per 4096-point transform, half the threads).  Measured on MI355X (passbench, 24 x 4096^2, 4 images per
+// launch, us per image): A 25.7 -> 25.2, C1 18.7 -> 17.2, C2 23.9 -> 23.1; at 2048 / 1024 points the 16-value form is slower
+// (fewer waves per transform: 2048^2 C2 6.8 -> 7.3; one 1024^2 image 26.0 -> 30.1 us), so it starts at 4096.
+// The inverse kernels of that form own ONE exchange buffer per thread group (FDR_ROWS_INV_NBUF1_MIN: the two packed pairs
+// hand their mirrored halves over one after the other, the exchanges take a second barrier): 37 KB instead of 74 KB of LDS,
+// four 256-thread workgroups per CU instead of two -- C1 17.2 -> 14.7 us per 4096^2 image (0.45 -> 0.57 of the roofline).
+#ifndef FDR_ROWS_ONE_V16_MIN
+#define FDR_ROWS_ONE_V16_MIN 12
+#endif
+#ifndef FDR_ROWS_ONE_V16_MAX
+#define FDR_ROWS_ONE_V16_MAX 12
+#endif
+#ifndef FDR_ROWS_INV_NBUF1_MIN
+#define FDR_ROWS_INV_NBUF1_MIN 12
+#endif
+// (The FORWARD kernel with one buffer -- pairs separated and stored one after the other, a lane pair writing the 64-byte half
+// of a line that its rows 2b, 2b+1 make up, four workgroups per CU -- was measured too: pass A 25.5 -> 28.5 us per 4096^2 image;
+// half-line stores cost more than the occupancy gains.  Not kept.)
 template <int LOGL>
 struct Rows4PackGeom {
-    static constexpr int T = Steps<LOGL>::T;
+    static constexpr int LOGV = (LOGL <= FDR_ROWS_ONE_V16_MAX && LOGL >= FDR_ROWS_ONE_V16_MIN) ? 4 : 3;
+    using St = Steps<LOGL, LOGV>;
+    static constexpr int T = St::T;
     static constexpr int G = T >= 256 ? 1 : 256 / T;
     static constexpr int THREADS = T * G;
+    // inverse kernels with ONE exchange buffer: as many workgroups per CU as the LDS admits, registers capped to match
+    static constexpr int INV_LDS = G * St::BUF * 8;
+    static constexpr int INV_WG_PER_CU = (LOGL >= FDR_ROWS_INV_NBUF1_MIN && LOGL == 12) ? ((160 * 1024) / INV_LDS > 4 ? 4 : (160 * 1024) / INV_LDS) : 1;
+    static constexpr int INV_WAVES_PER_SIMD = INV_WG_PER_CU * THREADS / 256 > 0 ? (INV_WG_PER_CU * THREADS / 256 > 8 ? 8 : INV_WG_PER_CU * THREADS / 256) : 1;
 };
 
 // Reads every register of a prefetched set through an empty asm: the compiler places the wait for those loads HERE (with
@@ -77,12 +106,12 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
         a.src_real = pick_image(a0.batch.src_real, blockIdx.y);
         a.dst_c = pick_image(a0.batch.spec, blockIdx.y);
     }
-    using St = Steps<LOGL>;
     using Geo = Rows4PackGeom<LOGL>;
+    using St = typename Geo::St;
     constexpr int G = Geo::G, T = St::T, L = St::L;
-    using Core = FftCore<LOGL, 2, 2, PolicyFast>;
+    using Core = FftCore<LOGL, 2, 2, PolicyFast, Geo::LOGV, (St::lr(0) == 1 && T >= 64 && FDR_SWAP0)>;
     __shared__ float2 lds[G * 2 * St::BUF];
-    const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
+    const int g = threadIdx.x >> St::LOGT, tid = Core::thread_index(threadIdx.x & (T - 1));
     float2* grp_lds = lds + g * 2 * St::BUF;
     const int M = a.M;
     const int r0 = (blockIdx.x * G + g) * 4;
@@ -92,7 +121,7 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
     typename Core::Bases bases;
     Core::init_bases(bases, tw_fwd, tid);
 
-    float2 z[2][8];
+    float2 z[2][Core::V];
     // common case first: all four rows and all L columns inside the image -> 32 unpredicated loads
     // from four wave-uniform row bases with one 32-bit per-thread offset
     const bool interior = (rr + 3 < a.src_rows) && (a.src_cols >= L);
@@ -160,7 +189,7 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
         const float2* buf = grp_lds + ((SEQ1 + (j >> 1)) & 1) * St::BUF;  // packed pair holding row j
         const bool odd = (j & 1) != 0;                            // row b of the pair (else row a)
 #pragma unroll
-        for (int i = 0; i < (HALF ? 4 : 8); ++i) {
+        for (int i = 0; i < (HALF ? L / 8 : L / 4) / (T / 4); ++i) {
             const int c = (tid >> 2) + (T / 4) * i;  // panel
             const int n0 = c * 4;
             float2 o[4];
@@ -219,9 +248,6 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
 //   LOGV = 4: 16 values per thread, T = L/16 threads: 8192-point rows as ONE 512-thread workgroup per CU with a
 //             256-register budget (the 8-value form needs 1024 threads at 128 registers and cannot hold a prefetch)
 // ---------------------------------------------------------------------------------------------
-#ifndef FDR_SWAP0
-#define FDR_SWAP0 1  // v_permlane32_swap exchange behind a radix-2 first step (8192-point transforms on the 16-value core)
-#endif
 #ifndef FDR_ROWS12_LOGV
 #define FDR_ROWS12_LOGV 3  // values per thread (log2) of the persistent row passes for rows of 4096 points (A/B builds)
 #endif
@@ -233,6 +259,9 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
 // only, where the alternative is a 1024-thread workgroup alone on its CU.
 #ifndef FDR_ROWS_PERS_MIN_LOG
 #define FDR_ROWS_PERS_MIN_LOG 13
+#endif
+#ifndef FDR_ROWS_INV_PERS_MIN_LOG  // the same for the inverse passes (C', C1, C2) alone
+#define FDR_ROWS_INV_PERS_MIN_LOG FDR_ROWS_PERS_MIN_LOG
 #endif
 template <int LOGL, int LOGV>
 struct RowsPersGeom {
@@ -520,10 +549,42 @@ __device__ __forceinline__ void rows4_load_direct(const RowArgs& a, int rr, int 
 }
 // z[0] = Y_a + i Y_b of rows 0, 1, z[1] of rows 2, 3; grp_lds: the thread group's two exchange buffers.  Barriers inside
 // (every thread of the workgroup must come here); returns with both buffers free again.
-template <int LOGL, class Core>
+// ONE_BUF: the thread group owns a single exchange buffer (more workgroups per CU): the two packed pairs hand their mirrored
+// halves over one after the other (two more barriers), same values.
+template <int LOGL, class Core, bool ONE_BUF = false>
 __device__ __forceinline__ void rows4_pack_mirror(int tid, const float2 (&y)[4][Core::V / 2], float2 (&z)[2][Core::V], float2* grp_lds) {
     using St = typename Core::St;
     constexpr int L = St::L, HQ = Core::RHO0 / 2;
+    if constexpr (ONE_BUF) {
+        float2* m = grp_lds;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            FDR_JITTER(3011 + p);
+#pragma unroll
+            for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+                for (int q = 0; q < HQ; ++q) {
+                    const int j = u * HQ + q, s = u * Core::RHO0 + q;
+                    const int n = Core::in_index(tid, u, q);
+                    const float2 ya = y[2 * p][j], yb = y[2 * p + 1][j];
+                    z[p][s] = make_float2(ya.x - yb.y, ya.y + yb.x);  // Y_a + i Y_b
+                    const int k = (L - n) & (L - 1);
+                    if (!(u == 0 && q == 0) || tid != 0) m[k] = make_float2(ya.x + yb.y, yb.x - ya.y);
+                }
+            __syncthreads();
+            FDR_JITTER(3013 + p);
+#pragma unroll
+            for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+                for (int q = HQ; q < Core::RHO0; ++q) z[p][u * Core::RHO0 + q] = m[Core::in_index(tid, u, q)];
+            if (tid == 0) {
+                z[p][0] = make_float2(y[2 * p][0].x, y[2 * p + 1][0].x);
+                z[p][HQ] = make_float2(y[2 * p][0].y, y[2 * p + 1][0].y);
+            }
+            __syncthreads();  // the next pair's hand-over (or the transform's first exchange) overwrites the buffer
+        }
+        return;
+    }
     float2* m0 = grp_lds;
     float2* m1 = grp_lds + St::BUF;
     FDR_JITTER(3001);
@@ -650,7 +711,7 @@ __device__ __forceinline__ void rows4_inv_epilogue(const RowArgs& a, const int r
 // HALF: the row spectra hold columns 0 .. N/2-1 only, column 0 packed as Y[m,0] + i Y[m,N/2] (see the forward
 // kernel); the upper half is rebuilt as the conjugate of the mirrored column (rows4_pack_mirror).
 template <int LOGL, bool HALF, int OUT = 0>
-__global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_packed_kernel(const RowArgs a0,
+__global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS, (HALF ? Rows4PackGeom<LOGL>::INV_WAVES_PER_SIMD : 1)) void fft_rows4_inv_packed_kernel(const RowArgs a0,
                                                                                           const float2* __restrict__ tw_fwd) {
     RowArgs a = a0;
     if (a0.batch.nimg > 1) {  // blockIdx.y = image
@@ -660,12 +721,13 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_pa
         a.mm_part = pick_image(a0.batch.mm_part, blockIdx.y);
     }
     float fscale = 0.f, fshift = 0.f;
-    using St = Steps<LOGL>;
     using Geo = Rows4PackGeom<LOGL>;
+    using St = typename Geo::St;
     constexpr int G = Geo::G, T = St::T;
-    using Core = FftCore<LOGL, 2, 2, PolicyFast>;
-    __shared__ float2 lds[G * 2 * St::BUF];
-    const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
+    constexpr int NBUF = (HALF && LOGL >= FDR_ROWS_INV_NBUF1_MIN) ? 1 : 2;  // 1: one exchange buffer per thread group (more workgroups per CU)
+    using Core = FftCore<LOGL, 2, NBUF, PolicyFast, Geo::LOGV, (St::lr(0) == 1 && T >= 64 && FDR_SWAP0)>;
+    __shared__ float2 lds[G * NBUF * St::BUF];
+    const int g = threadIdx.x >> St::LOGT, tid = Core::thread_index(threadIdx.x & (T - 1));
     const int M = a.M;
     const int r0 = (blockIdx.x * G + g) * 4;
     const bool active = r0 < M;
@@ -674,25 +736,25 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_inv_pa
     typename Core::Bases bases;
     Core::init_bases(bases, tw_fwd, tid);
 
-    float2 z[2][8];
+    float2 z[2][Core::V];
     if constexpr (HALF && LOGL >= 5) {  // direct half from memory, mirrored half through LDS
-        float2 y[4][4];
+        float2 y[4][Core::V / 2];
         rows4_load_direct<LOGL, Core>(a, rr, tid, y);
         // pass C2: the partials are folded BEHIND the group's own loads (a workgroup lives for one group here: a fold in
         // front of them adds its full memory latency to every workgroup -- measured +6 us per 4096^2 image)
         if constexpr (OUT == 2) block_fold_partials(a.mm_part, a.n_part, fscale, fshift);
-        rows4_pack_mirror<LOGL, Core>(tid, y, z, lds + g * 2 * St::BUF);
+        rows4_pack_mirror<LOGL, Core, NBUF == 1>(tid, y, z, lds + g * NBUF * St::BUF);
     } else {
-        float2 y[4][8];
+        float2 y[4][Core::V];
         rows4_load_raw<LOGL, HALF, Core>(a, rr, tid, y);
         if constexpr (OUT == 2) block_fold_partials(a.mm_part, a.n_part, fscale, fshift);
         rows4_pack<LOGL, HALF, Core>(tid, y, z);
     }
 
-    Core::template run<0, true>(z, lds + g * 2 * St::BUF, tw_fwd, bases, tid);
+    Core::template run<0, true>(z, lds + g * NBUF * St::BUF, tw_fwd, bases, tid);
 
     float mn = __builtin_inff(), mx = -__builtin_inff();
-    if (active) rows4_inv_epilogue<Core, OUT, 8>(a, r0, tid, z, fscale, fshift, mn, mx);
+    if (active) rows4_inv_epilogue<Core, OUT, Core::V>(a, r0, tid, z, fscale, fshift, mn, mx);
     if constexpr (OUT != 2) block_minmax_store(mn, mx, a.mm_part, (int)blockIdx.x);
 }
 
@@ -806,7 +868,7 @@ static int rows4_inv_pers_grid(int M, int num_cu, int nimg) {
 #endif
 template <int LOGL, int OUT>
 static hipError_t launch_rows4_inv_t(const RowArgs& a, const float2* tw, hipStream_t s, int groups, int nimg, dim3 grid, dim3 block) {
-    if constexpr (LOGL >= FDR_ROWS_PERS_MIN_LOG && FDR_ROWS_PERSISTENT) {
+    if constexpr (LOGL >= FDR_ROWS_INV_PERS_MIN_LOG && FDR_ROWS_PERSISTENT) {
         constexpr int LOGV = LOGL >= 13 ? 4 : (LOGL == 12 ? FDR_ROWS12_LOGV : 3);
         using PG = RowsPersGeom<LOGL, LOGV>;
         if (rows4_inv_use_pers<LOGL>(a.M, a.num_cu, nimg)) {
@@ -868,7 +930,7 @@ static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const f
 
 template <int LOGL>
 static int rows4_partials_t(int M, int num_cu, int nimg) {
-    if constexpr (LOGL >= FDR_ROWS_PERS_MIN_LOG && FDR_ROWS_PERSISTENT) {
+    if constexpr (LOGL >= FDR_ROWS_INV_PERS_MIN_LOG && FDR_ROWS_PERSISTENT) {
         if (rows4_inv_use_pers<LOGL>(M, num_cu, nimg)) return rows4_inv_pers_grid<LOGL>(M, num_cu, nimg);
     }
     return ((M + 3) / 4 + Rows4PackGeom<LOGL>::G - 1) / Rows4PackGeom<LOGL>::G;
