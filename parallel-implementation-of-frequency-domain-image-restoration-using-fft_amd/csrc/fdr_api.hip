@@ -421,7 +421,7 @@ int panel_stage_CE(fdr_plan* p, fdr_plan::Slot& w, int rows, int cols, float* d_
         a.src_c = w.work; a.mm_part = w.mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
         a.pstride = p->pstride; a.half = 1; a.num_cu = p->num_cu;
         a.out = d_out; a.out_rows = rows; a.out_cols = cols; a.out_stride = out_stride;
-        a.n_part = rows4_minmax_partials(p->logN, p->M, p->num_cu, 1);
+        a.n_part = rows4_minmax_partials(p->logN, p->M, p->num_cu, 1, p->half ? 1 : 0);
         if (a.n_part <= 0 || a.n_part > p->mm_part_cap) return fail(FDR_ERR_STATE, "fdr_wiener: min/max partial count out of range");
         {
             ScopedPass t(p, s, kPassRowsMinmax);
@@ -442,7 +442,7 @@ int panel_stage_CE(fdr_plan* p, fdr_plan::Slot& w, int rows, int cols, float* d_
     }
     {   // E: normalise to [0,1] and crop
         ScopedPass t(p, s, kPassNormalize);
-        const int n_part = rows4_minmax_partials(p->logN, p->M, p->num_cu, 1);
+        const int n_part = rows4_minmax_partials(p->logN, p->M, p->num_cu, 1, p->half ? 1 : 0);
         if (n_part <= 0 || n_part > p->mm_part_cap || n_part > 4096) return fail(FDR_ERR_STATE, "fdr_wiener: min/max partial count out of range");
         FDR_HIP(launch_normalize(w.raw, p->N, w.mm_part, n_part, nullptr, d_out, rows, cols, out_stride, s));
     }
@@ -469,7 +469,7 @@ int panel_stage_CE_batch(fdr_plan* p, fdr_plan::Slot* const* ws, int n, int rows
         a.src_c = ws[0]->work; a.mm_part = ws[0]->mm_part; a.mm_rows = mm_rows; a.mm_cols = mm_cols; a.M = p->M;
         a.pstride = p->pstride; a.half = 1; a.num_cu = p->num_cu;
         a.out = d_outs[0]; a.out_rows = rows; a.out_cols = cols; a.out_stride = out_stride;
-        a.n_part = rows4_minmax_partials(p->logN, p->M, p->num_cu, n);
+        a.n_part = rows4_minmax_partials(p->logN, p->M, p->num_cu, n, p->half ? 1 : 0);
         if (a.n_part <= 0 || a.n_part > p->mm_part_cap) return fail(FDR_ERR_STATE, "fdr_wiener: min/max partial count out of range");
         a.batch.nimg = n;
         for (int k = 0; k < kMaxGroup; ++k) {
@@ -500,7 +500,7 @@ int panel_stage_CE_batch(fdr_plan* p, fdr_plan::Slot* const* ws, int n, int rows
     }
     {
         ScopedPass t(p, s, kPassNormalizeN[n]);
-        const int n_part = rows4_minmax_partials(p->logN, p->M, p->num_cu, n);
+        const int n_part = rows4_minmax_partials(p->logN, p->M, p->num_cu, n, p->half ? 1 : 0);
         if (n_part <= 0 || n_part > p->mm_part_cap || n_part > 4096) return fail(FDR_ERR_STATE, "fdr_wiener: min/max partial count out of range");
         NormBatch nb{};
         nb.nimg = n;

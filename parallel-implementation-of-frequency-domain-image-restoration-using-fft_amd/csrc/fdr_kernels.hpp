@@ -102,7 +102,7 @@ hipError_t launch_cols(int logm, int mode, ColKind kind, const ColArgs& a, const
 // rows4: (ROW_IN_REAL -> ROW_OUT_COMPLEX[panel]) forward, (ROW_IN_COMPLEX[panel] -> ROW_OUT_REAL_MINMAX) inverse
 hipError_t launch_rows4(int logl, RowIn in, RowOut out, const RowArgs& a, const float2* tw_fwd, hipStream_t s);
 // min/max partials pass C' writes per image when `nimg` images share a launch on a device with num_cu CUs
-int rows4_minmax_partials(int logl, int M, int num_cu, int nimg);
+int rows4_minmax_partials(int logl, int M, int num_cu, int nimg, int half);
 // cols_panel: COL_FWD_FILTER (PSF spectrum -> W, in place) or COL_FUSED (FFT . W . IFFT)
 hipError_t launch_cols_panel(int logm, ColKind kind, const ColArgs& a, const float2* tw_fwd, hipStream_t s);
 

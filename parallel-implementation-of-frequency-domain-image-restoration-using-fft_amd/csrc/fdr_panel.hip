@@ -835,6 +835,190 @@ __global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<
     if constexpr (OUT != 2) block_minmax_store(mn, mx, a.mm_part, (int)blockIdx.x);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row passes for ONE small image (single-image calls, rows of 256 .. 2048 points, at most 2048 rows; BASELINE config 2).
+// A lone 1024^2 image is 256 four-row groups: the kernels above give each group to ONE thread group that runs its two
+// packed transforms one after the other (128 workgroups of two groups at 1024 points), and with nothing else in flight the
+// launch lasts as long as that dependent chain.  Here the two packed pairs of a group go to two thread groups of one
+// workgroup (B = 1 transform each, twice the waves on half the chain, one workgroup per group: 256 of them at 1024^2); the
+// step plan, policy and pack / separate formulas are those of the packed kernels, so the bits are the same.
+// ---------------------------------------------------------------------------------------------
+#ifndef FDR_ROWS_SPLIT
+#define FDR_ROWS_SPLIT 1
+#endif
+template <int LOGL>
+struct RowsSplitGeom {
+    using St = Steps<LOGL, 3>;
+    static constexpr int T = St::T;
+    static constexpr int THREADS = 2 * T;
+    static constexpr bool SWAP = St::lr(0) == 1 && T >= 64 && FDR_SWAP0;
+};
+static inline bool rows4_use_split(int logl, int M, int nimg, int half) {
+    return FDR_ROWS_SPLIT && nimg <= 1 && half && logl >= 8 && logl <= 11 && (M & 3) == 0 && M > 0 && M <= 2048;
+}
+
+template <int LOGL>
+__global__ __launch_bounds__(RowsSplitGeom<LOGL>::THREADS) void fft_rows4_fwd_split_kernel(const RowArgs a, const float2* __restrict__ tw_fwd) {
+    using Geo = RowsSplitGeom<LOGL>;
+    using St = typename Geo::St;
+    constexpr int T = St::T, L = St::L;
+    using Core = FftCore<LOGL, 1, 2, PolicyFast, 3, Geo::SWAP>;
+    __shared__ float2 lds[2 * 2 * St::BUF];
+    const int p = (int)(threadIdx.x >> St::LOGT);  // packed pair of the group: rows 2p, 2p + 1
+    const int tid = Core::thread_index((int)(threadIdx.x & (T - 1)));
+    float2* grp_lds = lds + p * 2 * St::BUF;
+    const int r0 = (int)blockIdx.x * 4;
+    const int ra = r0 + 2 * p, rb = ra + 1;
+
+    typename Core::Bases bases;
+    Core::init_bases(bases, tw_fwd, tid);
+
+    float2 z[1][8];
+    const float* __restrict__ rowa = a.src_real + (size_t)(ra < a.src_rows ? ra : 0) * a.src_stride;
+    const float* __restrict__ rowb = a.src_real + (size_t)(rb < a.src_rows ? rb : 0) * a.src_stride;
+#pragma unroll
+    for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+        for (int q = 0; q < Core::RHO0; ++q) {
+            const int n = Core::in_index(tid, u, q);
+            float xa = 0.f, xb = 0.f;
+            if (n < a.src_cols) {
+                if (ra < a.src_rows) xa = __builtin_nontemporal_load(rowa + n);
+                if (rb < a.src_rows) xb = __builtin_nontemporal_load(rowb + n);
+            }
+            z[0][u * Core::RHO0 + q] = make_float2(xa, xb);
+        }
+
+    Core::template run<0, false>(z, grp_lds, tw_fwd, bases, tid);
+
+    // the pair's packed spectrum in natural order into the buffer the last exchange did NOT use (free: its last readers
+    // passed that exchange's barrier), then the whole workgroup separates: a quad of lanes owns one 128-byte line
+    constexpr int SEQ1 = Core::SLOTS;
+    float2* mine = grp_lds + (SEQ1 & 1) * St::BUF;
+    FDR_JITTER(2031);
+#pragma unroll
+    for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+        for (int q = 0; q < Core::RHOL; ++q) mine[Core::out_index(tid, u, q)] = z[0][u * Core::RHOL + q];
+    __syncthreads();
+    FDR_JITTER(2032);
+    const int w = (int)threadIdx.x;
+    const int j = w & 3;                                                        // row inside the 4-row group
+    const float2* buf = lds + (j >> 1) * 2 * St::BUF + (SEQ1 & 1) * St::BUF;    // packed pair holding row j
+    const bool odd = (j & 1) != 0;                                              // row b of the pair (else row a)
+    constexpr int NIT = (L / 8) / (2 * T / 4);                                  // panels per lane (half spectrum)
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int c = (w >> 2) + (2 * T / 4) * i;  // panel
+        const int n0 = c * 4;
+        float2 o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float2 zn = buf[n0 + k];
+            const float2 zm = buf[(L - n0 - k) & (L - 1)];
+            o[k] = odd ? make_float2(0.5f * (zn.y + zm.y), 0.5f * (zm.x - zn.x))
+                       : make_float2(0.5f * (zn.x + zm.x), 0.5f * (zn.y - zm.y));
+        }
+        if (n0 == 0) {  // packed column: (X[0], X[N/2]), both real: Re/Im of Z[0] and Z[N/2]
+            const float2 z0 = buf[0], zq = buf[L / 2];
+            o[0] = odd ? make_float2(z0.y, zq.y) : make_float2(z0.x, zq.x);
+        }
+        store4(a.dst_c + (size_t)c * a.pstride + (size_t)(r0 + j) * 4, o[0], o[1], o[2], o[3]);
+    }
+}
+
+// OUT as in rows4_inv_epilogue: 0 raw real plane + min/max, 1 min/max only, 2 normalised and cropped
+template <int LOGL, int OUT>
+__global__ __launch_bounds__(RowsSplitGeom<LOGL>::THREADS) void fft_rows4_inv_split_kernel(const RowArgs a, const float2* __restrict__ tw_fwd) {
+    using Geo = RowsSplitGeom<LOGL>;
+    using St = typename Geo::St;
+    constexpr int T = St::T, L = St::L, V = 8;
+    using Core = FftCore<LOGL, 1, 2, PolicyFast, 3, Geo::SWAP>;
+    static_assert(Core::RHO0 >= 2 && Core::LOGR0 >= 2, "n = t + q Q with Q a multiple of 4");
+    constexpr int HQ = Core::RHO0 / 2;
+    __shared__ float2 lds[2 * 2 * St::BUF];
+    const int p = (int)(threadIdx.x >> St::LOGT);
+    const int tid = Core::thread_index((int)(threadIdx.x & (T - 1)));
+    float2* grp_lds = lds + p * 2 * St::BUF;
+    const int r0 = (int)blockIdx.x * 4;
+    const int ra = r0 + 2 * p, rb = ra + 1;
+
+    typename Core::Bases bases;
+    Core::init_bases(bases, tw_fwd, tid);
+
+    // direct half of the pair's two Hermitian row spectra (stored columns n < L/2), see rows4_load_direct
+    float2 ya[V / 2], yb[V / 2];
+    const unsigned ps = (unsigned)a.pstride;
+#pragma unroll
+    for (int u = 0; u < Core::NU0; ++u) {
+        const unsigned t = (unsigned)(tid + u * Core::T);
+        const unsigned off_d = (t >> 2) * ps + (t & 3u) + (unsigned)ra * 4u;
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) {
+            const float2* ptr = a.src_c + (size_t)((q << Core::LOGR0) >> 2) * ps + off_d;
+            ya[u * HQ + q] = ptr[0];
+            yb[u * HQ + q] = ptr[4];
+        }
+    }
+    float fscale = 0.f, fshift = 0.f;
+    if constexpr (OUT == 2) block_fold_partials(a.mm_part, a.n_part, fscale, fshift);  // behind the group's own loads
+
+    // Z[n] = Y_a[n] + i Y_b[n] for the direct half; conj(Y_a) + i conj(Y_b) belongs to index L - n: handed over in LDS
+    float2 z[1][V];
+    float2* m = grp_lds;
+    FDR_JITTER(3021);
+#pragma unroll
+    for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) {
+            const int jj = u * HQ + q, s = u * Core::RHO0 + q;
+            const int n = Core::in_index(tid, u, q);
+            const float2 y0 = ya[jj], y1 = yb[jj];
+            z[0][s] = make_float2(y0.x - y1.y, y0.y + y1.x);
+            const int k = (L - n) & (L - 1);
+            if (!(u == 0 && q == 0) || tid != 0) m[k] = make_float2(y0.x + y1.y, y1.x - y0.y);
+        }
+    __syncthreads();
+    FDR_JITTER(3022);
+#pragma unroll
+    for (int u = 0; u < Core::NU0; ++u)
+#pragma unroll
+        for (int q = HQ; q < Core::RHO0; ++q) z[0][u * Core::RHO0 + q] = m[Core::in_index(tid, u, q)];
+    if (tid == 0) {  // n = 0 (DC) and n = L/2 (Nyquist): real values packed as (DC, Nyquist) in stored column 0
+        z[0][0] = make_float2(ya[0].x, yb[0].x);
+        z[0][HQ] = make_float2(ya[0].y, yb[0].y);
+    }
+    __syncthreads();  // the transform's first exchange may overwrite the buffer
+
+    Core::template run<0, true>(z, grp_lds, tw_fwd, bases, tid);
+
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+#pragma unroll
+    for (int u = 0; u < Core::NUL; ++u)
+#pragma unroll
+        for (int q = 0; q < Core::RHOL; ++q) {
+            const int n = Core::out_index(tid, u, q);
+            const float va = z[0][u * Core::RHOL + q].x, vb = z[0][u * Core::RHOL + q].y;  // rows ra, rb
+            if constexpr (OUT == 0) {
+                a.dst_real[(size_t)ra * L + n] = va;
+                a.dst_real[(size_t)rb * L + n] = vb;
+            }
+            if constexpr (OUT == 2) {
+                const float pa = va * fscale, pb = vb * fscale;
+                if (n < a.out_cols) {
+                    if (ra < a.out_rows) __builtin_nontemporal_store(pa + fshift, a.out + (size_t)ra * a.out_stride + n);
+                    if (rb < a.out_rows) __builtin_nontemporal_store(pb + fshift, a.out + (size_t)rb * a.out_stride + n);
+                }
+            } else {
+                if (n < a.mm_cols) {
+                    if (ra < a.mm_rows) { mn = fminf(mn, va); mx = fmaxf(mx, va); }
+                    if (rb < a.mm_rows) { mn = fminf(mn, vb); mx = fmaxf(mx, vb); }
+                }
+            }
+        }
+    if constexpr (OUT != 2) block_minmax_store(mn, mx, a.mm_part, (int)blockIdx.x);
+}
+
 // persistent pass C' is used when a workgroup gets more than one group (else there is nothing to overlap); always for
 // 8192-point rows (see launch_rows4_t)
 template <int LOGL>
@@ -889,6 +1073,25 @@ static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const f
     const int groups = (a.M + 3) / 4;
     const int nimg = a.batch.nimg > 1 ? a.batch.nimg : 1;
     const dim3 grid((groups + Geo::G - 1) / Geo::G, nimg), block(Geo::THREADS);
+    if constexpr (LOGL >= 8 && LOGL <= 11) {
+        if (rows4_use_split(LOGL, a.M, nimg, a.half)) {  // one small image: two thread groups per 4-row group (see above)
+            using SG = RowsSplitGeom<LOGL>;
+            const dim3 sgrid(a.M / 4), sblock(SG::THREADS);
+            if (in == ROW_IN_REAL && out == ROW_OUT_COMPLEX) {
+                if (a.src_rows <= 0 || a.src_cols <= 0) return hipErrorInvalidValue;
+                hipLaunchKernelGGL((fft_rows4_fwd_split_kernel<LOGL>), sgrid, sblock, 0, s, a, tw);
+            } else if (in == ROW_IN_COMPLEX && out == ROW_OUT_REAL_MINMAX) {
+                hipLaunchKernelGGL((fft_rows4_inv_split_kernel<LOGL, 0>), sgrid, sblock, 0, s, a, tw);
+            } else if (in == ROW_IN_COMPLEX && out == ROW_OUT_MINMAX_ONLY) {
+                hipLaunchKernelGGL((fft_rows4_inv_split_kernel<LOGL, 1>), sgrid, sblock, 0, s, a, tw);
+            } else if (in == ROW_IN_COMPLEX && out == ROW_OUT_NORMALIZED) {
+                hipLaunchKernelGGL((fft_rows4_inv_split_kernel<LOGL, 2>), sgrid, sblock, 0, s, a, tw);
+            } else {
+                return hipErrorInvalidValue;
+            }
+            return hipGetLastError();
+        }
+    }
     if (in == ROW_IN_REAL && out == ROW_OUT_COMPLEX) {
         if constexpr (LOGL >= FDR_ROWS_PERS_MIN_LOG && FDR_ROWS_PERSISTENT) {
             constexpr int LOGV = LOGL >= 13 ? 4 : (LOGL == 12 ? FDR_ROWS12_LOGV : 3);
@@ -929,7 +1132,8 @@ static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const f
 }
 
 template <int LOGL>
-static int rows4_partials_t(int M, int num_cu, int nimg) {
+static int rows4_partials_t(int M, int num_cu, int nimg, int half) {
+    if (rows4_use_split(LOGL, M, nimg, half)) return M / 4;  // one workgroup, one partial per 4-row group
     if constexpr (LOGL >= FDR_ROWS_INV_PERS_MIN_LOG && FDR_ROWS_PERSISTENT) {
         if (rows4_inv_use_pers<LOGL>(M, num_cu, nimg)) return rows4_inv_pers_grid<LOGL>(M, num_cu, nimg);
     }
@@ -957,8 +1161,8 @@ hipError_t launch_rows4(int logl, RowIn in, RowOut out, const RowArgs& a, const 
     return hipErrorInvalidValue;
 }
 
-int rows4_minmax_partials(int logl, int M, int num_cu, int nimg) {
-    FDR_DISPATCH_LOG(logl, rows4_partials_t<LG>(M, num_cu, nimg));
+int rows4_minmax_partials(int logl, int M, int num_cu, int nimg, int half) {
+    FDR_DISPATCH_LOG(logl, rows4_partials_t<LG>(M, num_cu, nimg, half));
     return 0;
 }
 
@@ -1125,6 +1329,8 @@ __device__ __forceinline__ gchar* uniform_gptr(const void* p) {
     return (gchar*)(((unsigned long long)hi << 32) | lo);
 }
 // 32 bytes at (uniform base) + (32-bit lane byte offset): global_load_dwordx4 v, v_off, s[base:base+1] {offset:16}.
+// (Round 3: the tile loads as non-temporal loads -- to keep the shared filter W in L2 longer -- measured 35.4 -> 35.6 us per
+// 4096^2 image, FDR_WPIECE 2 instead of 4: 36.5 us; neither kept.)
 // (HIP's float4, field by field: with native vector types the two halves reach the register arrays as <2 x float>
 // stores, which SROA does not promote -- the arrays then live in scratch memory.)
 #define FDR_GLOAD32(ub, lane_bytes, a, b, c, d)                                                       \
