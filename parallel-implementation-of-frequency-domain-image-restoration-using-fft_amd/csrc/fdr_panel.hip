@@ -1709,21 +1709,37 @@ struct PanelSplitGeom {
     static constexpr int THREADS = 4 * T;
 };
 
-template <int LOGM>
+// (Round 3: the same kernel as the BATCHED pass B' at 4096 points -- 1024 threads per tile, one exchange buffer per column
+// (NBUF = 1, 148 KB: one workgroup per CU), W requested up front, grid over (tile, image) as the tile kernel -- measured 43.3
+// against 34.6 us per image: with one tile in flight per CU nothing overlaps its memory phases.  The tile kernel stays.)
+template <int LOGM, int NBUF = 2>
 __global__ __launch_bounds__(PanelSplitGeom<LOGM>::THREADS) void fft_cols_panel_split_kernel(
-    float2* __restrict__ data, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const unsigned pstride, const int packed0) {
+    const PanelBatch pb, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const unsigned pstride, const int packed0,
+    const int img_shift) {
     using Geo = PanelSplitGeom<LOGM>;
     using St = typename Geo::St;
     constexpr int M = St::L, V = St::V;
-    using Core = FftCore<LOGM, 1, 2, PolicyFast, Geo::LOGV, false>;
-    constexpr int GRP = 2 * St::BUF + ((24 - (2 * St::BUF) % 32) & 31);  // float2 elements per group, = 24 (mod 32): 48 dwords (mod 64)
+    using Core = FftCore<LOGM, 1, NBUF, PolicyFast, Geo::LOGV, false>;
+    constexpr int GRP = NBUF * St::BUF + ((24 - (NBUF * St::BUF) % 32) & 31);  // float2 elements per group, = 24 (mod 32): 48 dwords (mod 64)
     static_assert(GRP % 32 == 24, "group stride");
     __shared__ float2 lds[4 * GRP];
     const int c = (int)(threadIdx.x & 3);   // column of the panel
     const int tid = (int)(threadIdx.x >> 2);  // logical thread of that column's transform
     float2* grp_lds = lds + c * GRP;
-    float2* __restrict__ col = data + (size_t)blockIdx.x * pstride + c;           // element (m, c) of the panel at col[4 m]
-    const float2* __restrict__ wcol = filt + (size_t)blockIdx.x * pstride + c;
+    int img = 0, tl = (int)blockIdx.x;
+    if (img_shift >= 0) {  // flat grid: the workgroups that share a tile (and its slice of W) are neighbours on one XCD
+        const int b = (int)blockIdx.x, jj = b >> 3;
+        img = jj & ((1 << img_shift) - 1);
+        tl = ((jj >> img_shift) << 3) | (b & 7);
+    } else {
+        img = (int)blockIdx.y;
+    }
+    // element (m, c) of the panel lies at panel[4 m + c]: a wave-uniform base per (u, q) slot (SGPRs) plus ONE 32-bit lane
+    // offset for every access of the kernel -- no 64-bit per-lane address lives in VGPRs (see uniform_gptr)
+    float2* __restrict__ panel = pick_image(pb.data, img) + (size_t)tl * pstride;
+    const float2* __restrict__ wpanel = filt + (size_t)tl * pstride;
+    const float2* __restrict__ wcol = wpanel + c;
+    const unsigned lane_off = (unsigned)threadIdx.x * 8u;  // (4 tid + c) float2 elements
 
     typename Core::Bases bases;
     Core::init_bases(bases, tw_fwd, tid);
@@ -1732,19 +1748,27 @@ __global__ __launch_bounds__(PanelSplitGeom<LOGM>::THREADS) void fft_cols_panel_
 #pragma unroll
     for (int u = 0; u < Core::NU0; ++u)
 #pragma unroll
-        for (int q = 0; q < Core::RHO0; ++q) v[0][u * Core::RHO0 + q] = col[(size_t)Core::in_index(tid, u, q) * 4];
+        for (int q = 0; q < Core::RHO0; ++q) {
+            const gchar* ub = uniform_gptr(panel + (unsigned)(((q << Core::LOGR0) + u * Core::T) * 4));
+            v[0][u * Core::RHO0 + q] = *reinterpret_cast<const float2*>((const char*)ub + lane_off);
+        }
 #pragma unroll
     for (int u = 0; u < Core::NUL; ++u)
 #pragma unroll
-        for (int q = 0; q < Core::RHOL; ++q) w[u * Core::RHOL + q] = wcol[(size_t)Core::out_index(tid, u, q) * 4];
+        for (int q = 0; q < Core::RHOL; ++q) {
+            const gchar* ub = uniform_gptr(wpanel + (unsigned)(((q << Core::LOGOUT) + u * Core::T) * 4));
+            w[u * Core::RHOL + q] = *reinterpret_cast<const float2*>((const char*)ub + lane_off);
+        }
 
     Core::template run<0, false>(v, grp_lds, tw_fwd, bases, tid);
 
     constexpr int SEQ = Core::SLOTS;
-    const bool packed_tile = packed0 && blockIdx.x == 0;  // uniform per workgroup
+    const bool packed_tile = packed0 && tl == 0;  // uniform per workgroup
     if (packed_tile) {  // column 0 of panel 0 carries DC + i Nyquist (see packed_column_filter): finished by its own thread group
-        // (the buffer of slot SEQ is free: its last readers passed the barrier of the exchange after it)
-        float2* bufc = grp_lds + (SEQ & 1) * St::BUF;
+        // (two buffers: the buffer of slot SEQ is free -- its last readers passed the barrier of the exchange after it;
+        //  one buffer: it was read by the last exchange, hence the barrier)
+        float2* bufc = grp_lds + (SEQ % NBUF) * St::BUF;
+        if constexpr (NBUF == 1) __syncthreads();
         FDR_JITTER(4031);
         if (c == 0) {
 #pragma unroll
@@ -1782,10 +1806,17 @@ __global__ __launch_bounds__(PanelSplitGeom<LOGM>::THREADS) void fft_cols_panel_
     Core::permute_out_to_in(v);
     Core::template run<SEQ, true>(v, grp_lds, tw_fwd, bases, tid);
 
+    {
+        unsigned lo = (unsigned)threadIdx.x * 8u;  // opaque copy: recomputed here instead of living across both transforms
+        asm volatile("" : "+v"(lo));
 #pragma unroll
-    for (int u = 0; u < Core::NUL; ++u)
+        for (int u = 0; u < Core::NUL; ++u)
 #pragma unroll
-        for (int q = 0; q < Core::RHOL; ++q) col[(size_t)Core::out_index(tid, u, q) * 4] = v[0][u * Core::RHOL + q];
+            for (int q = 0; q < Core::RHOL; ++q) {
+                gchar* ub = uniform_gptr(panel + (unsigned)(((q << Core::LOGOUT) + u * Core::T) * 4));
+                *reinterpret_cast<float2*>((char*)ub + lo) = v[0][u * Core::RHOL + q];
+            }
+    }
 }
 
 #ifndef FDR_COLS_SPLIT
@@ -1807,8 +1838,8 @@ static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const floa
         for (int k = pb.nimg; k < kMaxGroup; ++k) pb.data[k] = pb.data[0];
         if constexpr (FDR_COLS_SPLIT && LOGM >= 8 && LOGM <= 11) {
             if (pb.nimg == 1) {  // a single small image: latency, not bandwidth (see fft_cols_panel_split_kernel)
-                hipLaunchKernelGGL((fft_cols_panel_split_kernel<LOGM>), dim3(npanels), dim3(PanelSplitGeom<LOGM>::THREADS), 0, s, pb.data[0], a.filt, tw,
-                                   (unsigned)ps, a.packed0);
+                hipLaunchKernelGGL((fft_cols_panel_split_kernel<LOGM, 2>), dim3(npanels), dim3(PanelSplitGeom<LOGM>::THREADS), 0, s, pb, a.filt, tw,
+                                   (unsigned)ps, a.packed0, -1);
                 return hipGetLastError();
             }
         }
