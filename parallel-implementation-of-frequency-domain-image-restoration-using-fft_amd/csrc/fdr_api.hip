@@ -1309,7 +1309,7 @@ int fdr_slab_rows_fft_dev(fdr_plan* p, float* d_complex, int rows, int dim, int 
 int fdr_slab_pack_dev(const void* d_src, int rows, int ld, int parts, const int* counts, int elem_size, void* d_dst, void* stream) {
     if (!d_src || !d_dst || !counts || rows < 0 || ld <= 0) return fail(FDR_ERR_ARG, "fdr_slab_pack_dev: bad argument");
     hipError_t e = launch_slab_pack(d_src, rows, ld, parts, counts, elem_size, d_dst, (hipStream_t)stream);
-    if (e == hipErrorInvalidValue) return fail(FDR_ERR_ARG, "fdr_slab_pack_dev: 1..16 parts whose counts sum to ld, element size 4 or 8");
+    if (e == hipErrorInvalidValue) return fail(FDR_ERR_ARG, "fdr_slab_pack_dev: 1..16 parts with non-negative counts that sum to ld, element size 4 or 8");
     FDR_HIP(e);
     return FDR_OK;
 }

@@ -521,7 +521,10 @@ hipError_t launch_slab_pack(const void* src, int rows, int ld, int parts, const 
     SlabParts sp{};
     sp.parts = parts;
     int d = 0;
-    for (int k = 0; k < parts; ++k) { sp.counts[k] = counts[k]; sp.displs[k] = d; d += counts[k]; }
+    for (int k = 0; k < parts; ++k) {
+        if (counts[k] < 0) return hipErrorInvalidValue;  // (a negative block could still sum to ld)
+        sp.counts[k] = counts[k]; sp.displs[k] = d; d += counts[k];
+    }
     if (d != ld) return hipErrorInvalidValue;
     if (rows <= 0 || ld <= 0) return hipSuccess;
     const dim3 grid((ld + 255) / 256, rows), block(256);

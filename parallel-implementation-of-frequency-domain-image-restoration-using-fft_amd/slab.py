@@ -49,8 +49,8 @@ class SlabTransposer:
     """Distributed transpose of a global R x C array held as row slabs (fft/fft_mpi.cpp:170-279): rank g owns
     rows [rdis[g], rdis[g] + rcnt[g]) before and rows [cdis[g], ...) of the C x R transpose after."""
 
-    def __init__(self, comm, R, C, stream=None):
-        self.comm, self.R, self.C, self.stream = comm, int(R), int(C), stream
+    def __init__(self, comm, R, C):
+        self.comm, self.R, self.C = comm, int(R), int(C)
         self.rcnt, self.rdis = calculate_distribution(R, comm.world)
         self.ccnt, self.cdis = calculate_distribution(C, comm.world)
         self.lr, self.lc = self.rcnt[comm.rank], self.ccnt[comm.rank]
@@ -59,7 +59,7 @@ class SlabTransposer:
         """slab: device float32 tensor of lr x C elements (elem_floats = 2 complex, 1 real) -> lc x R elements."""
         import torch
         es = 4 * elem_floats
-        st = ctypes.c_void_p(int(self.stream) if self.stream else 0)
+        st = _current_stream()  # the kernels, torch's allocations / copies and the collective all order on torch's current stream
         packed = torch.empty(self.lr * self.C * elem_floats, dtype=torch.float32, device=slab.device)
         counts = (ctypes.c_int * len(self.ccnt))(*self.ccnt)
         if self.lr > 0:
@@ -75,18 +75,29 @@ class SlabTransposer:
         return out
 
 
+def _current_stream():
+    import torch
+    return ctypes.c_void_p(int(torch.cuda.current_stream().cuda_stream))
+
+
 def wiener_slab(comm, img_rows_local, rows, cols, psf, K, device=0, norm_area=NORM_PADDED, stream=None):
     """One channel of the operator on a row-slab decomposition.  img_rows_local: this rank's rows of the UNPADDED image
     (float32 [n, cols], rows [first, first + n) with the split of the PADDED row count M: ranks whose slab lies in the
-    padding pass an empty array); returns this rank's rows of the restored, cropped image as a numpy array."""
+    padding pass an empty array); returns this rank's rows of the restored, cropped image as a numpy array.
+    Everything -- the fdr_slab_* kernels, torch's allocations and copies, the all-to-all -- is ordered on ONE stream:
+    torch's current stream, or `stream` (a hipStream_t handle) made current for the duration of the call."""
     import torch
+    if stream:
+        with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=torch.device("cuda", device))):
+            return wiener_slab(comm, img_rows_local, rows, cols, psf, K, device=device, norm_area=norm_area, stream=None)
     M, N = nextPowerOfTwo(rows), nextPowerOfTwo(cols)
     dev = torch.device("cuda", device)
-    st = ctypes.c_void_p(int(stream) if stream else 0)
+    torch.cuda.set_device(dev)
+    st = _current_stream()
     rcnt, rdis = calculate_distribution(M, comm.world)
     lr, first = rcnt[comm.rank], rdis[comm.rank]
-    t_fwd = SlabTransposer(comm, M, N, stream)   # rows -> columns
-    t_bwd = SlabTransposer(comm, N, M, stream)   # columns -> rows
+    t_fwd = SlabTransposer(comm, M, N)   # rows -> columns
+    t_bwd = SlabTransposer(comm, N, M)   # columns -> rows
     lc = t_fwd.lc
     with Plan(M, N, MODE_PARITY, device=device, flags=FLAG_TABLES_ONLY) as plan:
         h = plan._h

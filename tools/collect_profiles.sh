@@ -6,10 +6,13 @@
 #   * rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no trace options beside them) of
 #     bench.py --streams 1 at both sizes (bench's own launch grouping: the counters are per LAUNCH of 4 / 2 images), and on a
 #     known-size float4 copy (calibration of FETCH_SIZE on gfx950)
-#   * the 2-rank rehearsal of the N > 1 bench path on this one GPU (backend gloo, --one-device), weak and strong scaling
+#   * the 2-rank rehearsal of the N > 1 bench path on this one GPU (backend gloo, --one-device), weak and strong scaling, and
+#     the same with --bcast-filter (rank 0's filter W broadcast to the other rank instead of recomputed)
+#   * BASELINE config 2 as written -- ONE 1024^2 image per step (bench.py --batch 1 --streams 1 --group 1), also 512^2 and
+#     2048^2 -- with the rocprofv3 kernel trace of the 1024^2 run, and passbench's per-pass view of the same
 #   usage: tools/collect_profiles.sh <tag>
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -30,6 +33,17 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -o cal -- ./too
 # N > 1 path of bench.py on the one GPU: two ranks, gloo, both on cuda:0 (torchrun is started before anything touches the GPU)
 python3 bench.py --gpus 2 --backend gloo --one-device --size 2048 --batch 32 --steps 5 --warmup 2 --repeats 3 --no-psf-recompute > $OUT/two_rank_weak.log 2>&1; echo "two_rank_weak rc=$?" >> $OUT/status.txt
 python3 bench.py --gpus 2 --backend gloo --one-device --size 2048 --total-batch 63 --steps 5 --warmup 2 --repeats 3 --no-psf-recompute > $OUT/two_rank_strong.log 2>&1; echo "two_rank_strong rc=$?" >> $OUT/status.txt
+python3 bench.py --gpus 2 --backend gloo --one-device --size 2048 --batch 16 --steps 5 --warmup 2 --repeats 3 --no-psf-recompute --no-parity-leg --bcast-filter > $OUT/two_rank_bcast_filter.log 2>&1; echo "two_rank_bcast_filter rc=$?" >> $OUT/status.txt
+# BASELINE config 2 as written: ONE image per step, one stream, one image per launch (and the neighbouring sizes)
+for S in 512 1024 2048; do
+  python3 bench.py --size $S --batch 1 --streams 1 --group 1 --steps 200 --warmup 20 --repeats 5 --no-cpu-baseline --no-psf-recompute --no-parity-leg > $OUT/single_image_$S.log 2>&1; echo "single_image_$S rc=$?" >> $OUT/status.txt
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_single_1024 -o kt -- python3 bench.py --size 1024 --batch 1 --streams 1 --group 1 --steps 200 --warmup 20 --repeats 1 --no-cpu-baseline --no-psf-recompute --no-parity-leg > $OUT/kt_single_1024.log 2>&1; echo "kt_single_1024 rc=$?" >> $OUT/status.txt
+[ -x tools/microbench/passbench ] || /opt/rocm/bin/hipcc -O2 -o tools/microbench/passbench tools/microbench/passbench.cpp -ldl
+PKG="$GRAFT_REPO_ROOT/parallel-implementation-of-frequency-domain-image-restoration-using-fft_amd"
+for S in 256 512 1024 2048; do tools/microbench/passbench $PKG/libfdr.so $S 8 20 1 1 >> $OUT/single_image_passbench.log 2>&1; done
+tools/microbench/passbench $PKG/libfdr.so 4096 24 10 2 4 >> $OUT/passbench_4096.log 2>&1
+tools/microbench/passbench $PKG/libfdr.so 8192 6 6 2 2 >> $OUT/passbench_8192.log 2>&1
 # BASELINE config 5 on the one GPU (512 x 2048^2, device resident) and config 2's size (1024^2)
 python3 bench.py --size 2048 --total-batch 512 --steps 10 --warmup 2 --repeats 3 > $OUT/config5_one_gpu.log 2>&1; echo "config5_one_gpu rc=$?" >> $OUT/status.txt
 python3 bench.py --size 1024 --batch 256 --steps 10 --warmup 2 --repeats 3 > $OUT/config2_size.log 2>&1; echo "config2_size rc=$?" >> $OUT/status.txt

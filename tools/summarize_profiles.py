@@ -91,7 +91,24 @@ def main():
         for r in rows:
             print(size, r[0], "read %.1f MB write %.1f MB" % (r[5] / 1e6, r[6] / 1e6))
     json.dump(tj, open(tj_path, "w"), indent=1, sort_keys=True)
+    kts = glob.glob(os.path.join(src, "kt_single_1024", "**", "*kernel_stats.csv"), recursive=True)
+    if kts:  # ONE 1024^2 image per step: device durations of the four launches
+        stats = list(csv.DictReader(open(kts[0])))
+        with open(os.path.join(dst, "%s_kernel_stats_single_1024.csv" % tag), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(stats[0].keys()))
+            w.writeheader()
+            for r in stats:
+                if "fdr::" in r["Name"]:
+                    w.writerow(r)
+    for name in ("single_image_passbench.log", "passbench_4096.log", "passbench_8192.log"):
+        pth = os.path.join(src, name)
+        if os.path.exists(pth):
+            txt = open(pth).read().replace(ROOT + "/", "")
+            import re
+            txt = re.sub(r"/tmp/code/[^ ]*/repo/", "", txt)
+            open(os.path.join(dst, "%s_%s" % (tag, name)), "w").write(txt)
     for name in ("bench_line.json", "bench_line_streams1_4096.json", "bench_line_streams1_8192.json", "two_rank_weak.log", "two_rank_strong.log",
+                 "two_rank_bcast_filter.log", "single_image_512.log", "single_image_1024.log", "single_image_2048.log",
                  "config5_one_gpu.log", "config2_size.log", "config4_size.log", "bench_raw_plane.log", "status.txt"):
         pth = os.path.join(src, name)
         if os.path.exists(pth):
