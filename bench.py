@@ -220,8 +220,8 @@ def main():
         fdr.synth_image_dev(imgs.data_ptr(), B * P, seed, first_index=first_image * P, device=local_rank, stream=stream)
     torch.cuda.synchronize()
 
-    def step():
-        plan.wiener_batch_dev(imgs.data_ptr(), P, B, S, S, S, outs.data_ptr(), P, S, fdr.NORM_PADDED, stream=stream)
+    # (arguments converted once: with one small image per step the call itself is ~20 us)
+    step = plan.prepared_batch_dev(imgs.data_ptr(), P, B, S, S, S, outs.data_ptr(), P, S, fdr.NORM_PADDED, stream=stream)
 
     # one untimed priming step as part of the setup (code objects load and the internal streams / workspaces are touched
     # on first use); the W warm-up steps of the contract follow inside timed_steps.  The K timed steps are repeated

@@ -296,6 +296,22 @@ class Plan:
                                             ctypes.c_void_p(int(d_out)), out_pitch, out_stride, int(norm_area),
                                             _stream(stream)))
 
+    def prepared_batch_dev(self, d_imgs, img_pitch, count, rows, cols, stride, d_out, out_pitch, out_stride,
+                           norm_area=NORM_PADDED, stream=None):
+        """The same call as wiener_batch_dev with its arguments converted ONCE: returns a zero-argument callable.  For callers
+        that repeat one call many times (a single small image per step is a 20 us call: the per-call ctypes conversions of
+        twelve arguments are then a measurable part of it)."""
+        fn = lib.fdr_wiener_batch_f32_dev
+        args = (self._h, ctypes.c_void_p(int(d_imgs)), ctypes.c_size_t(img_pitch), ctypes.c_int(count), ctypes.c_int(rows), ctypes.c_int(cols),
+                ctypes.c_int(stride), ctypes.c_void_p(int(d_out)), ctypes.c_size_t(out_pitch), ctypes.c_int(out_stride), ctypes.c_int(int(norm_area)),
+                _stream(stream))
+
+        def call():
+            rc = fn(*args)
+            if rc != 0:
+                _check(rc)
+        return call
+
     def wiener_batch(self, imgs, out=None, norm_area=NORM_PADDED):
         """Host arrays [count, rows, cols] in, restored planes out; H2D / compute / D2H of consecutive images
         overlap (pinned arrays from host_alloc() are copied by DMA in place)."""
