@@ -254,6 +254,13 @@ typedef struct fdr_batch_desc {
     int steps, warmup;   /* synthetic run: timed / untimed passes over the shard (steps >= 1) */
     int nstreams, group; /* fdr_plan_set_batching of every worker (0, 0 = defaults) */
     int norm_area;       /* FDR_NORM_* */
+    int bcast_filter;    /* 0: every worker prepares the PSF spectrum / filter itself (default; cheaper than moving it);
+                            1: worker 0 prepares it and the others RECEIVE its bytes -- ncclBroadcast over RCCL (xGMI) when
+                            the device ordinals are distinct, device / peer copies when an ordinal repeats or RCCL cannot be
+                            loaded: the MPI_Bcast / MPI_Scatterv of the padded PSF in the reference's MPI variant
+                            (fft/fft_mpi.cpp:334-378).  Needs count >= n_devices.  fdr_batch_stats::filter_path says which.
+                            2: the same, and the RCCL path is taken even for a single device entry (a broadcast to itself:
+                            exercises the library and the call on a one-GPU machine). */
 } fdr_batch_desc;
 
 #define FDR_BATCH_MAX_DEVICES 16
@@ -267,7 +274,11 @@ typedef struct fdr_batch_stats {
     double wall_ms;                        /* all workers: from the common start to the last one's finish */
     long long images_done;                 /* sum over workers of images x passes */
     double mpixels_per_s;                  /* images_done * rows * cols / wall_ms */
+    int filter_path;                       /* FDR_FILTER_*: how the workers came by their filter */
 } fdr_batch_stats;
+#define FDR_FILTER_LOCAL 0          /* prepared by every worker */
+#define FDR_FILTER_RCCL_BROADCAST 1 /* worker 0's, by ncclBroadcast */
+#define FDR_FILTER_PEER_COPY 2      /* worker 0's, by device-to-device / peer copies */
 int fdr_batch_run(const fdr_batch_desc* desc, fdr_batch_stats* stats);
 
 /* -- single-image multi-GPU mode: the reference's MPI variant splits ONE image into row slabs and

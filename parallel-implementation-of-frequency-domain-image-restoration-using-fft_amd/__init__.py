@@ -44,14 +44,14 @@ class BatchDesc(ctypes.Structure):
                 ("count", ctypes.c_int), ("rows", ctypes.c_int), ("cols", ctypes.c_int), ("stride", ctypes.c_int), ("out_stride", ctypes.c_int),
                 ("imgs_host", ctypes.POINTER(ctypes.c_void_p)), ("outs_host", ctypes.POINTER(ctypes.c_void_p)),
                 ("synth_seed", ctypes.c_uint64), ("steps", ctypes.c_int), ("warmup", ctypes.c_int),
-                ("nstreams", ctypes.c_int), ("group", ctypes.c_int), ("norm_area", ctypes.c_int)]
+                ("nstreams", ctypes.c_int), ("group", ctypes.c_int), ("norm_area", ctypes.c_int), ("bcast_filter", ctypes.c_int)]
 
 
 class BatchStats(ctypes.Structure):
     """fdr_batch_stats of include/fdr.h"""
     _fields_ = [("n_devices", ctypes.c_int), ("first", ctypes.c_int * 16), ("images", ctypes.c_int * 16),
                 ("elapsed_ms", ctypes.c_double * 16), ("checksum", ctypes.c_double * 16), ("status", ctypes.c_int * 16),
-                ("wall_ms", ctypes.c_double), ("images_done", ctypes.c_longlong), ("mpixels_per_s", ctypes.c_double)]
+                ("wall_ms", ctypes.c_double), ("images_done", ctypes.c_longlong), ("mpixels_per_s", ctypes.c_double), ("filter_path", ctypes.c_int)]
 
 
 class FdrError(RuntimeError):
@@ -430,7 +430,7 @@ def wienerDeblur_myfft_unpadded(img, psf, K, mode=MODE_PARITY, device=0):
 
 
 def batch_run(devices, M, N, count, rows=None, cols=None, mode=MODE_FAST, flags=0, psf=None, psf_size=50, psf_angle=30.0, K=0.01,
-              imgs=None, seed=0x5EED0005, steps=1, warmup=0, nstreams=0, group=0, norm_area=NORM_PADDED):
+              imgs=None, seed=0x5EED0005, steps=1, warmup=0, nstreams=0, group=0, norm_area=NORM_PADDED, bcast_filter=False):
     """fdr_batch_run: `count` independent images sharded over `devices` (ordinals, may repeat) by the reference's
     calculate_distribution rule, one host thread + plan per entry.  imgs = float32 [count, rows, cols] host array (results
     returned) or None for the device-resident synthetic run.  Returns (stats dict, outputs or None)."""
@@ -458,12 +458,14 @@ def batch_run(devices, M, N, count, rows=None, cols=None, mode=MODE_FAST, flags=
         d.imgs_host, d.outs_host = pin, pout
     d.synth_seed, d.steps, d.warmup = int(seed), int(steps), int(warmup)
     d.nstreams, d.group, d.norm_area = int(nstreams), int(group), int(norm_area)
+    d.bcast_filter = int(bcast_filter)  # False / True / 2 (RCCL even for one device entry)
     st = BatchStats()
     _check(lib.fdr_batch_run(ctypes.byref(d), ctypes.byref(st)))
     n = st.n_devices
     stats = {"first": list(st.first[:n]), "images": list(st.images[:n]), "elapsed_ms": list(st.elapsed_ms[:n]),
              "checksum": list(st.checksum[:n]), "status": list(st.status[:n]), "wall_ms": st.wall_ms,
-             "images_done": st.images_done, "mpixels_per_s": st.mpixels_per_s}
+             "images_done": st.images_done, "mpixels_per_s": st.mpixels_per_s,
+             "filter_path": ("local", "rccl_broadcast", "peer_copy")[st.filter_path] if 0 <= st.filter_path <= 2 else st.filter_path}
     return stats, outs
 
 

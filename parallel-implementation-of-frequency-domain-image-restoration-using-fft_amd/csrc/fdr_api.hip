@@ -5,6 +5,7 @@
 #include "fdr_kernels.hpp"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1378,22 +1379,29 @@ __global__ void checksum_kernel(const float* __restrict__ x, size_t count, doubl
     if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-int batch_worker_run(const fdr_batch_desc* d, BatchWorker* w, std::chrono::steady_clock::time_point* t_start_out) {
-    fdr_plan* plan = nullptr;
+// `prepared`: a plan that already holds its filter (fdr_batch_desc::bcast_filter: created and filled by the calling thread,
+// which has synchronised the device); the worker owns it from here on.  nullptr: the worker builds plan and filter itself.
+int batch_worker_run(const fdr_batch_desc* d, BatchWorker* w, std::chrono::steady_clock::time_point* t_start_out, fdr_plan* prepared) {
+    fdr_plan* plan = prepared;
     float *d_in = nullptr, *d_out = nullptr;
     double* d_part = nullptr;
     hipStream_t stream = nullptr;
     int rc = FDR_OK;
     auto body = [&]() -> int {
         if (w->count == 0) return FDR_OK;
-        int r = fdr_plan_create(w->device, d->M, d->N, d->mode, d->flags, &plan);
-        if (r != FDR_OK) return r;
+        int r = FDR_OK;
+        if (!plan) {
+            r = fdr_plan_create(w->device, d->M, d->N, d->mode, d->flags, &plan);
+            if (r != FDR_OK) return r;
+        }
         // the worker's stream exists BEFORE the PSF spectrum is queued, and the generated PSF is prepared ON it: the batches
         // below run on this (non-blocking) stream and its forks, which never synchronise with the null stream by themselves
         // (fdr_set_psf with a host PSF synchronises before it returns)
         FDR_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        if (d->psf_host) r = fdr_set_psf(plan, d->psf_host, d->psf_rows, d->psf_cols, d->psf_stride, d->K);
-        else r = fdr_set_psf_motion(plan, d->psf_size, d->psf_angle_deg, d->K, stream);
+        if (!prepared) {
+            if (d->psf_host) r = fdr_set_psf(plan, d->psf_host, d->psf_rows, d->psf_cols, d->psf_stride, d->K);
+            else r = fdr_set_psf_motion(plan, d->psf_size, d->psf_angle_deg, d->K, stream);
+        }
         if (r != FDR_OK) return r;
         if (d->imgs_host) {  // host images: the pipelined host batch over this worker's shard
             const auto t0 = std::chrono::steady_clock::now();
@@ -1458,6 +1466,79 @@ int batch_worker_run(const fdr_batch_desc* d, BatchWorker* w, std::chrono::stead
 
 }  // namespace
 
+namespace {
+
+// RCCL, resolved at run time (no link-time dependency: a process that never broadcasts a filter never loads it, and inside
+// a PyTorch process the copy of the library that torch has already mapped is the one that answers)
+struct Rccl {
+    typedef void* comm_t;
+    int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*GroupStart)(void) = nullptr;
+    int (*GroupEnd)(void) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    Rccl() {
+        void* h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+        if (!h) return;
+        *(void**)&CommInitAll = dlsym(h, "ncclCommInitAll");
+        *(void**)&CommDestroy = dlsym(h, "ncclCommDestroy");
+        *(void**)&GroupStart = dlsym(h, "ncclGroupStart");
+        *(void**)&GroupEnd = dlsym(h, "ncclGroupEnd");
+        *(void**)&Broadcast = dlsym(h, "ncclBroadcast");
+        *(void**)&GetErrorString = dlsym(h, "ncclGetErrorString");
+        ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && Broadcast;
+    }
+};
+
+// fdr_batch_desc::bcast_filter: plans[0] holds the filter; every other plan gets its bytes.  Distinct devices: ONE
+// ncclBroadcast over a communicator of all of them (RCCL over xGMI: the MPI_Bcast of fft/fft_mpi.cpp:334-378); an ordinal
+// that repeats (two workers on one device -- RCCL refuses that) or a missing RCCL: device-to-device / peer copies.
+// Returns the path taken (FDR_FILTER_*) or a negative status.
+int distribute_filter(const std::vector<fdr_plan*>& plans, float K, bool force_rccl) {
+    const int G = (int)plans.size();
+    const size_t bytes = plans[0]->ws_elems * sizeof(float2);
+    bool distinct = true;
+    for (int a = 0; a < G; ++a)
+        for (int b = a + 1; b < G; ++b) distinct = distinct && plans[a]->device != plans[b]->device;
+    int path = FDR_FILTER_PEER_COPY;
+    static Rccl rccl;  // (thread-safe initialisation; loaded on first use)
+    if (distinct && (G > 1 || force_rccl) && rccl.ok) {
+        std::vector<int> devs(G);
+        for (int g = 0; g < G; ++g) devs[g] = plans[g]->device;
+        std::vector<Rccl::comm_t> comms(G, nullptr);
+        int nr = rccl.CommInitAll(comms.data(), G, devs.data());
+        if (nr == 0) {
+            nr = rccl.GroupStart();
+            for (int g = 0; g < G && nr == 0; ++g) {
+                if (hipSetDevice(devs[g]) != hipSuccess) { nr = -1; break; }
+                nr = rccl.Broadcast(plans[g]->filt, plans[g]->filt, bytes, 0 /* ncclChar */, 0, comms[g], nullptr);
+            }
+            const int ne = rccl.GroupEnd();
+            if (nr == 0) nr = ne;
+            for (int g = 0; g < G; ++g)
+                if (hipSetDevice(devs[g]) == hipSuccess) (void)hipDeviceSynchronize();
+            for (int g = 0; g < G; ++g)
+                if (comms[g]) (void)rccl.CommDestroy(comms[g]);
+        }
+        if (nr != 0) return fail(FDR_ERR_HIP, std::string("fdr_batch_run: RCCL broadcast of the filter failed: ") + (rccl.GetErrorString && nr > 0 ? rccl.GetErrorString(nr) : "error"));
+        path = FDR_FILTER_RCCL_BROADCAST;
+    } else {
+        for (int g = 1; g < G; ++g) {
+            FDR_HIP(hipSetDevice(plans[g]->device));
+            if (plans[g]->device == plans[0]->device) FDR_HIP(hipMemcpy(plans[g]->filt, plans[0]->filt, bytes, hipMemcpyDeviceToDevice));
+            else FDR_HIP(hipMemcpyPeer(plans[g]->filt, plans[g]->device, plans[0]->filt, plans[0]->device, bytes));
+        }
+    }
+    for (int g = 1; g < G; ++g) { plans[g]->K = K; plans[g]->have_psf = true; }
+    return path;
+}
+
+}  // namespace
+
 extern "C" int fdr_batch_run(const fdr_batch_desc* d, fdr_batch_stats* st) {
     if (!d) return fail(FDR_ERR_ARG, "fdr_batch_run: null descriptor");
     if (d->n_devices < 1 || d->n_devices > FDR_BATCH_MAX_DEVICES || !d->devices)
@@ -1482,11 +1563,30 @@ extern "C" int fdr_batch_run(const fdr_batch_desc* d, fdr_batch_stats* st) {
         ws[g].first = first;
         first += ws[g].count;
     }
+    // bcast_filter: worker 0's filter for everyone -- plans created and the filter distributed here, before the workers start
+    std::vector<fdr_plan*> prepared((size_t)G, nullptr);
+    int filter_path = FDR_FILTER_LOCAL;
+    if (d->bcast_filter && (G > 1 || d->bcast_filter == 2) && d->count >= G) {  // (every worker has at least one image, so every plan is used)
+        int prc = FDR_OK;
+        for (int g = 0; g < G && prc == FDR_OK; ++g) prc = fdr_plan_create(ws[g].device, d->M, d->N, d->mode, d->flags, &prepared[g]);
+        if (prc == FDR_OK) {
+            if (d->psf_host) prc = fdr_set_psf(prepared[0], d->psf_host, d->psf_rows, d->psf_cols, d->psf_stride, d->K);
+            else prc = fdr_set_psf_motion(prepared[0], d->psf_size, d->psf_angle_deg, d->K, nullptr);
+        }
+        if (prc == FDR_OK && (hipSetDevice(prepared[0]->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess))
+            prc = fail(FDR_ERR_HIP, "fdr_batch_run: preparing the filter on worker 0's device failed");
+        if (prc == FDR_OK) { filter_path = distribute_filter(prepared, d->K, d->bcast_filter == 2); if (filter_path < 0) prc = filter_path; }
+        if (prc != FDR_OK) {
+            const std::string msg0 = g_last_error;
+            for (auto* pl : prepared) fdr_plan_destroy(pl);
+            return fail(prc, "fdr_batch_run: " + msg0);
+        }
+    }
     const auto t_launch = std::chrono::steady_clock::now();
     for (int g = 0; g < G; ++g) { starts[g] = t_launch; ws[g].t_end = t_launch; }
     std::vector<std::thread> threads;
-    for (int g = 1; g < G; ++g) threads.emplace_back(batch_worker_run, d, &ws[g], &starts[g]);
-    batch_worker_run(d, &ws[0], &starts[0]);  // worker 0 on the calling thread
+    for (int g = 1; g < G; ++g) threads.emplace_back(batch_worker_run, d, &ws[g], &starts[g], prepared[g]);
+    batch_worker_run(d, &ws[0], &starts[0], prepared[0]);  // worker 0 on the calling thread
     for (auto& t : threads) t.join();
     int rc = FDR_OK;
     std::string msg;
@@ -1512,6 +1612,7 @@ extern "C" int fdr_batch_run(const fdr_batch_desc* d, fdr_batch_stats* st) {
         st->wall_ms = any ? std::chrono::duration<double, std::milli>(t_last - t_first).count() : 0.0;
         st->images_done = done;
         st->mpixels_per_s = st->wall_ms > 0.0 ? (double)done * d->rows * d->cols / 1e6 / (st->wall_ms * 1e-3) : 0.0;
+        st->filter_path = filter_path;
     }
     if (rc != FDR_OK) return fail(rc, "fdr_batch_run: " + msg);
     return FDR_OK;

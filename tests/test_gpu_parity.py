@@ -340,6 +340,17 @@ def test_phase_times_and_batch_run(fdr, oracle):
         for i in range(2):
             ref4 += float(q.wiener(oracle.synth_image(0x5EED0006, i * 64 * 8192, 64 * 8192).reshape(64, 8192)).astype(np.float64).sum())
     assert abs(sum(st4["checksum"]) - ref4) < 1e-3, (sum(st4["checksum"]), ref4)
+    # bcast_filter: worker 0 prepares the filter, the others receive its bytes.  Three workers on ONE device: RCCL refuses a
+    # repeated ordinal, so this takes the copy path; a single device entry with bcast_filter = 2 goes through RCCL itself
+    # (communicator of one, broadcast to itself): library, symbols and call signature are exercised on the one GPU
+    st5, _ = fdr.batch_run([0, 0, 0], 256, 256, 6, mode=fdr.MODE_FAST, psf_size=15, psf_angle=30.0, seed=0x5EED0005, steps=1, warmup=0, bcast_filter=True)
+    assert st5["filter_path"] == "peer_copy" and st5["images_done"] == 6 and abs(sum(st5["checksum"]) - ref_sum) < 1e-3, st5
+    st6, _ = fdr.batch_run([0], 256, 256, 6, mode=fdr.MODE_FAST, psf_size=15, psf_angle=30.0, seed=0x5EED0005, steps=1, warmup=0, bcast_filter=2)
+    assert st6["filter_path"] == "rccl_broadcast" and abs(sum(st6["checksum"]) - ref_sum) < 1e-3, st6
+    st7, outs7 = fdr.batch_run([0, 0], 128, 256, 5, rows=100, cols=200, mode=fdr.MODE_PARITY, psf=psf, imgs=imgs, bcast_filter=True)
+    assert st7["filter_path"] == "peer_copy"
+    _assert_same(outs7, one, "fdr_batch_run with the filter handed from worker 0 (host images, parity mode)")
+    assert st2["filter_path"] == "local"
     with pytest.raises(fdr.FdrError):
         fdr.batch_run([0, 99], 128, 256, 2, rows=100, cols=200, psf=psf, imgs=imgs[:2])  # device ordinal out of range
     with pytest.raises(fdr.FdrError):
@@ -707,6 +718,20 @@ def test_filter_block_export_import_between_plans(fdr, oracle):
             _assert_same(b.wiener(img), a.wiener(img), "imported filter block, mode %d" % mode)
             if mode == fdr.MODE_PARITY:
                 _assert_same(b.wiener(img), oracle.serial_channel(img, psf, 0.01), "imported filter block vs oracle")
+
+
+def test_rccl_single_rank_smoke():
+    """The collectives of the batched mode under torch.distributed's "nccl" backend (= RCCL) on the one GPU of the box: a
+    one-rank process group in a child process (tests/_nccl_worker.py)."""
+    import json
+    import subprocess
+    import sys
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    env = dict(_os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + _os.getpid() % 300), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, _os.path.join(root, "tests", "_nccl_worker.py")], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["ok"] is True and out["backend"] == "nccl", out
 
 
 def test_cat_picture_through_both_clis(fdr, oracle, tmp_path):
