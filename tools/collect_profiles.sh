@@ -2,7 +2,8 @@
 # Runs on the GPU box (through gpurun), ONE call for the whole evidence set of a round, all from the build in the tree:
 #   * python bench.py (defaults)                         -> bench_line.json  (the line the driver will see)
 #   * rocprofv3 --kernel-trace --stats of bench.py --streams 1 at 4096^2 and 8192^2 (un-overlapped kernel durations;
-#     the launch grouping is bench's default, so the averages are per launch as bench's roofline reports them)
+#     the launch grouping is bench's default, so the averages are per launch as bench's roofline reports them; run with
+#     --no-batch-check --no-parity-leg: the check's single-image launches of the SAME kernels would be averaged in)
 #   * rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no trace options beside them) of
 #     bench.py --streams 1 at both sizes (bench's own launch grouping: the counters are per LAUNCH of 4 / 2 images), and on a
 #     known-size float4 copy (calibration of FETCH_SIZE on gfx950)
@@ -23,10 +24,10 @@ grep '^{' $OUT/bench_default.log | tail -n 1 > $OUT/bench_line.json
 python3 bench.py --raw-plane --no-cpu-baseline --no-psf-recompute > $OUT/bench_raw_plane.log 2>&1; echo "bench_raw_plane rc=$?" >> $OUT/status.txt
 for S in 4096 8192; do
   if [ $S = 8192 ]; then B="--batch 12 --steps 6 --warmup 2"; else B="--batch 48 --steps 10 --warmup 3"; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$S -o kt -- python3 bench.py --size $S $B --streams 1 --repeats 1 --no-cpu-baseline --no-psf-recompute > $OUT/kt_$S.log 2>&1; echo "kt_$S rc=$?" >> $OUT/status.txt
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$S -o kt -- python3 bench.py --size $S $B --streams 1 --repeats 1 --no-cpu-baseline --no-psf-recompute --no-parity-leg --no-batch-check > $OUT/kt_$S.log 2>&1; echo "kt_$S rc=$?" >> $OUT/status.txt
   grep '^{' $OUT/kt_$S.log | tail -n 1 > $OUT/bench_line_streams1_$S.json
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$S -o fetch -- python3 bench.py --size $S --steps 2 --warmup 1 --batch 8 --streams 1 --repeats 1 --no-cpu-baseline --no-psf-recompute > $OUT/fetch_$S.log 2>&1; echo "fetch_$S rc=$?" >> $OUT/status.txt
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$S -o write -- python3 bench.py --size $S --steps 2 --warmup 1 --batch 8 --streams 1 --repeats 1 --no-cpu-baseline --no-psf-recompute > $OUT/write_$S.log 2>&1; echo "write_$S rc=$?" >> $OUT/status.txt
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$S -o fetch -- python3 bench.py --size $S --steps 2 --warmup 1 --batch 8 --streams 1 --repeats 1 --no-cpu-baseline --no-psf-recompute --no-parity-leg --no-batch-check > $OUT/fetch_$S.log 2>&1; echo "fetch_$S rc=$?" >> $OUT/status.txt
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$S -o write -- python3 bench.py --size $S --steps 2 --warmup 1 --batch 8 --streams 1 --repeats 1 --no-cpu-baseline --no-psf-recompute --no-parity-leg --no-batch-check > $OUT/write_$S.log 2>&1; echo "write_$S rc=$?" >> $OUT/status.txt
 done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -o cal -- ./tools/microbench/membench > $OUT/cal_fetch.log 2>&1; echo "cal_fetch rc=$?" >> $OUT/status.txt
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -o cal -- ./tools/microbench/membench > $OUT/cal_write.log 2>&1; echo "cal_write rc=$?" >> $OUT/status.txt

@@ -62,6 +62,17 @@ def main():
                 for r in stats:
                     if "fdr::" in r["Name"]:
                         w.writerow(r)
+        tr = glob.glob(os.path.join(src, "kt_%d" % size, "**", "*kernel_trace.csv"), recursive=True)
+        if tr:  # the same trace split by launch grid: a kernel's one-image and grouped launches are different things
+            acc = collections.defaultdict(list)
+            for r in csv.DictReader(open(tr[0])):
+                if "fdr::" in r["Kernel_Name"]:
+                    acc[(r["Kernel_Name"], r["Grid_Size_X"], r["Grid_Size_Y"], r["Workgroup_Size_X"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            with open(os.path.join(dst, "%s_kernel_stats_by_grid_%d.csv" % (tag, size)), "w", newline="") as f:
+                w = csv.writer(f)
+                w.writerow(["Name", "Grid_Size_X", "Grid_Size_Y", "Workgroup_Size_X", "Calls", "AverageNs", "MedianNs", "MinNs", "MaxNs"])
+                for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+                    w.writerow(list(k) + [len(v), "%.1f" % (sum(v) / len(v)), "%.1f" % statistics.median(v), min(v), max(v)])
         fe_f = glob.glob(os.path.join(src, "fetch_%d" % size, "**", "*counter_collection.csv"), recursive=True)
         wr_f = glob.glob(os.path.join(src, "write_%d" % size, "**", "*counter_collection.csv"), recursive=True)
         if not (fe_f and wr_f):
