@@ -65,6 +65,15 @@ def test_reference_drivers_compile_unchanged_against_include(tmp_path):
     assert "$(REF)/serial.cpp" in mk and "$(REF)/gpu.cpp" in mk
 
 
+def test_opencv_stand_in_host_functions(fdr, tmp_path):
+    """tools/cli/cv_shim_test.cpp: the cv:: free functions of include/fdr_cv.hpp that never touch the device -- PNG / PPM round
+    trips through imwrite / imread, imshow's FDR_IMSHOW_DIR behaviour, convertTo, BGR <-> Lab, norm, copyMakeBorder,
+    getRotationMatrix2D, Size comparison -- checked on the host (cv::warpAffine is a device call: GPU tests)."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools", "cli"), "-s", "cv_shim_test"])
+    r = subprocess.run([os.path.join(ROOT, "tools", "cli", "cv_shim_test"), str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "cv shim ok" in r.stdout, (r.returncode, r.stdout[-800:], r.stderr[-800:])
+
+
 def test_integer_helpers_match_reference_semantics(fdr):
     # utils.hpp:27-37 / :50-52
     assert [fdr.nextPowerOfTwo(n) for n in (0, 1, 2, 3, 782, 1920, 4097)] == [1, 1, 2, 4, 1024, 2048, 8192]
