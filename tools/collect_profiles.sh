@@ -17,7 +17,7 @@ TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-make -s -C tools/microbench membench 2>/dev/null || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/microbench/membench tools/microbench/membench.hip
+make -s -C tools/microbench membench
 python3 bench.py > $OUT/bench_default.log 2>&1; echo "bench_default rc=$?" >> $OUT/status.txt
 grep '^{' $OUT/bench_default.log | tail -n 1 > $OUT/bench_line.json
 # the same with passes C' + E (raw real plane, 36 B/pixel) instead of the default two-sweep C1 + C2 (32 B/pixel)
@@ -40,11 +40,12 @@ for S in 512 1024 2048; do
   python3 bench.py --size $S --batch 1 --streams 1 --group 1 --steps 200 --warmup 20 --repeats 5 --no-cpu-baseline --no-psf-recompute --no-parity-leg > $OUT/single_image_$S.log 2>&1; echo "single_image_$S rc=$?" >> $OUT/status.txt
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_single_1024 -o kt -- python3 bench.py --size 1024 --batch 1 --streams 1 --group 1 --steps 200 --warmup 20 --repeats 1 --no-cpu-baseline --no-psf-recompute --no-parity-leg > $OUT/kt_single_1024.log 2>&1; echo "kt_single_1024 rc=$?" >> $OUT/status.txt
-[ -x tools/microbench/passbench ] || /opt/rocm/bin/hipcc -O2 -o tools/microbench/passbench tools/microbench/passbench.cpp -ldl
+make -s -C tools/microbench passbench seam_bench
 PKG="$GRAFT_REPO_ROOT/parallel-implementation-of-frequency-domain-image-restoration-using-fft_amd"
 for S in 256 512 1024 2048; do tools/microbench/passbench $PKG/libfdr.so $S 8 20 1 1 >> $OUT/single_image_passbench.log 2>&1; done
 tools/microbench/passbench $PKG/libfdr.so 4096 24 10 2 4 >> $OUT/passbench_4096.log 2>&1
 tools/microbench/passbench $PKG/libfdr.so 8192 6 6 2 2 >> $OUT/passbench_8192.log 2>&1
+(timeout -k 5 60 tools/microbench/seam_bench 256 256 200; timeout -k 5 60 tools/microbench/seam_bench 128 256 200; timeout -k 5 60 tools/microbench/seam_bench 256 512 200) > $OUT/seam_bench.log 2>&1; echo "seam_bench rc=$?" >> $OUT/status.txt
 # BASELINE config 5 on the one GPU (512 x 2048^2, device resident) and config 2's size (1024^2)
 python3 bench.py --size 2048 --total-batch 512 --steps 10 --warmup 2 --repeats 3 > $OUT/config5_one_gpu.log 2>&1; echo "config5_one_gpu rc=$?" >> $OUT/status.txt
 python3 bench.py --size 1024 --batch 256 --steps 10 --warmup 2 --repeats 3 > $OUT/config2_size.log 2>&1; echo "config2_size rc=$?" >> $OUT/status.txt
