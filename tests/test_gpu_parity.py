@@ -787,7 +787,11 @@ def test_drop_in_cli(fdr, tmp_path):
     import re as _re
     for label in ("2. H2D Copy", "4. GPU Compute", "5. D2H Copy", "3. Pre-process", "1. Allocation"):
         vals = [float(v) for v in _re.findall(_re.escape("[" + label + "]") + r"\s*Time: ([0-9.eE+-]+) ms", r.stdout)]
-        assert len(vals) == 3 and all(v > 0 for v in vals), (label, vals)  # warm-up + optimized + naive
+        assert len(vals) == 3, (label, vals)  # warm-up + optimized + naive
+        if label == "1. Allocation":  # the timed _optimized call REUSES a plan of the per-thread cache (here even the warm-up
+            assert vals[1] == 0 and vals[2] > 0, vals  # does: the serial leg created the parity-mode plan); _naive never does
+        else:
+            assert all(v > 0 for v in vals), (label, vals)
     rgb = np.asarray(Image.open(png).convert("RGB"), dtype=np.float32) / 255.0  # (330, 640, 3)
     h, w = rgb.shape[:2]
     planes = np.fromfile(out_raw, dtype=np.float32).reshape(3, h, w)  # B, G, R
