@@ -163,15 +163,16 @@ struct fdr_plan {
     hipEvent_t fork = nullptr;
     size_t ws_elems = 0;  // elements of one work / raw buffer
     bool two_sweep = true;           // FDR_OPT_TWO_SWEEP_NORM: passes C1 + C2 instead of C' + E (fast half-spectrum path)
+    size_t ce_cache_bytes = (size_t)160 << 20;  // FDR_OPT_CE_CACHE_MB: spectra one C1 + C2 launch pair may touch (0 = whole group at once)
     // FDR_OPT_BATCH_GRAPH: the launches of one fdr_wiener_batch_f32_dev call (fork, every pass of every group on the
     // internal streams, join) captured once as a hipGraph and replayed while the call's arguments stay the same
     struct GraphKey {
         const float* in; float* out; size_t in_pitch, out_pitch; int count, rows, cols, stride, out_stride, norm_area, nstreams, group;
-        bool two_sweep; float K;
+        bool two_sweep; float K; size_t ce_cache;
         bool operator==(const GraphKey& o) const {
             return in == o.in && out == o.out && in_pitch == o.in_pitch && out_pitch == o.out_pitch && count == o.count && rows == o.rows &&
                    cols == o.cols && stride == o.stride && out_stride == o.out_stride && norm_area == o.norm_area && nstreams == o.nstreams &&
-                   group == o.group && two_sweep == o.two_sweep && K == o.K;
+                   group == o.group && two_sweep == o.two_sweep && K == o.K && ce_cache == o.ce_cache;
         }
     };
     // host-pointer batch (fdr_wiener_batch_*_f32): three streams, three images in flight; created on first use and kept --
@@ -764,6 +765,10 @@ int fdr_plan_set_option(fdr_plan* p, int option, long long value) {
             if (value != 0 && value != 1) return fail(FDR_ERR_ARG, "fdr_plan_set_option: FDR_OPT_BATCH_GRAPH takes 0 or 1");
             p->batch_graph = value != 0;
             return FDR_OK;
+        case FDR_OPT_CE_CACHE_MB:
+            if (value < 0 || value > (1 << 20)) return fail(FDR_ERR_ARG, "fdr_plan_set_option: FDR_OPT_CE_CACHE_MB takes 0 .. 1048576");
+            p->ce_cache_bytes = (size_t)value << 20;
+            return FDR_OK;
         case FDR_OPT_TWO_SWEEP_NORM:
             if (value != 0 && value != 1) return fail(FDR_ERR_ARG, "fdr_plan_set_option: FDR_OPT_TWO_SWEEP_NORM takes 0 or 1");
             p->two_sweep = value != 0;
@@ -910,7 +915,7 @@ int fdr_wiener_batch_f32_dev(fdr_plan* p, const float* d_imgs, size_t img_pitch,
     // Not with per-kernel profiling (host-side event pairs).
     if (p->batch_graph && p->panel && !p->timer.enabled) {
         const fdr_plan::GraphKey key{d_imgs, d_out, img_pitch, out_pitch, count, rows, cols, stride, out_stride, norm_area, p->nstreams, p->group,
-                                     p->two_sweep, p->K};
+                                     p->two_sweep, p->K, p->ce_cache_bytes};
         if (!(p->graph_exec && key == p->graph_key)) {
             if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
             if (!p->cap_stream) FDR_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
@@ -962,7 +967,25 @@ int batch_enqueue(fdr_plan* p, const float* d_imgs, size_t img_pitch, int count,
             for (int k = 0; k < n; ++k) { ins[k] = d_imgs + (size_t)(i0 + k) * img_pitch; outs[k] = d_out + (size_t)(i0 + k) * out_pitch; }
             rc = panel_stage_A_batch(p, ws, n, ins, rows, cols, stride, s);
             if (rc == FDR_OK) rc = panel_stage_B(p, ws, n, s);
-            if (rc == FDR_OK) rc = panel_stage_CE_batch(p, ws, n, rows, cols, outs, out_stride, mm_rows, mm_cols, s);
+            // The two inverse row passes (C1: extremes, C2: the same transform again, normalised) read the spectrum twice.
+            // Launched over all n images of a group at 4096^2 they touch 4 x 64 MiB between the two reads of a line -- more
+            // than the 256 MiB Infinity Cache keeps -- so they go in chunks whose spectra stay inside it (p->ce_cache_bytes,
+            // FDR_OPT_CE_CACHE_MB): 2 images at 4096^2 (89.2 -> 87.9 us per image, 2 streams x 4), everything at once at 2048^2
+            // and below (16 MiB per image: one chunk; smaller launches only cost there: 21.3 -> 25.3 us), and no split where one
+            // image's spectrum alone exceeds the budget (8192^2: 256 MiB, measured no difference).
+            int chunk = n;
+            {
+                const size_t spec_bytes = p->ws_elems * sizeof(float2);
+                if (p->ce_cache_bytes > 0 && spec_bytes <= p->ce_cache_bytes) {
+                    const size_t c = p->ce_cache_bytes / spec_bytes;
+                    if (c < (size_t)n) chunk = (int)c;
+                }
+            }
+            for (int k0 = 0; k0 < n && rc == FDR_OK; k0 += chunk) {
+                const int m = n - k0 < chunk ? n - k0 : chunk;
+                if (m == 1) rc = panel_stage_CE(p, *ws[k0], rows, cols, outs[k0], out_stride, mm_rows, mm_cols, s);
+                else rc = panel_stage_CE_batch(p, ws + k0, m, rows, cols, outs + k0, out_stride, mm_rows, mm_cols, s);
+            }
             continue;
         }
         for (int k = 0; k < n && rc == FDR_OK; ++k)

@@ -27,12 +27,32 @@ PASS_OF = {
 }
 
 
-def counter(path, name):
-    d = collections.defaultdict(list)
+def counter(path, name, grids=None):
+    """Counter values per kernel name; when `grids` (a dict) is given, only the dispatches of each kernel's MOST FREQUENT
+    launch grid are kept and that grid (threads) is recorded in it."""
+    raw = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == name:
-            d[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return d
+            raw[r["Kernel_Name"]][int(r["Grid_Size"])].append(float(r["Counter_Value"]))
+    d = {}
+    for k, by_grid in raw.items():
+        if grids is None:
+            d[k] = [v for vs in by_grid.values() for v in vs]
+        else:
+            g = max(by_grid, key=lambda gg: len(by_grid[gg]))
+            d[k] = by_grid[g]
+            grids[k] = g
+    return collections.defaultdict(list, d)
+
+
+# threads one IMAGE's launch of a kernel has (one-group row kernels: M/4 groups x 256 threads; column tiles: N/8 tiles x T)
+def images_of(kname, grid, size, default):
+    lg = size.bit_length() - 1
+    if "fft_rows4_fwd_packed_kernel<%d" % lg in kname or "fft_rows4_inv_packed_kernel<%d" % lg in kname:
+        return max(1, round(grid / ((size // 4) * 256)))
+    if "fft_cols_panel_fused16_kernel<%d>" % lg in kname:
+        return max(1, round(grid / ((size // 8) * (size // 16))))
+    return default
 
 
 def main():
@@ -77,9 +97,10 @@ def main():
         wr_f = glob.glob(os.path.join(src, "write_%d" % size, "**", "*counter_collection.csv"), recursive=True)
         if not (fe_f and wr_f):
             continue
-        fe, wr = counter(fe_f[0], "FETCH_SIZE"), counter(wr_f[0], "WRITE_SIZE")
+        fgrids, wgrids = {}, {}
+        fe, wr = counter(fe_f[0], "FETCH_SIZE", fgrids), counter(wr_f[0], "WRITE_SIZE", wgrids)
         traffic, rows = {}, []
-        images = 4 if size <= 4096 else 2  # images per launch of bench.py's default grouping (what the PMC runs used)
+        default_images = 4 if size <= 4096 else 2  # images per launch of bench.py's default grouping (what the PMC runs used)
         for kname, vals in fe.items():
             for key, pname in PASS_OF.items():
                 if key.startswith("fft_rows4_inv_"):  # last template argument: 0 raw plane (C'), 1 min/max only (C1), 2 normalised (C2)
@@ -89,13 +110,14 @@ def main():
                     rd = statistics.median(vals) * round(fetch_factor) * 1024.0
                     wv = [v for k, v in wr.items() if k == kname]
                     wt = statistics.median(wv[0]) * 1024.0 if wv else 0.0
+                    images = images_of(kname, fgrids.get(kname, 0), size, default_images)
                     traffic[pname] = {"per_launch": rd + wt, "images": images}
-                    rows.append((pname, kname[:90], len(vals), statistics.median(vals), statistics.median(wv[0]) if wv else 0, rd, wt))
+                    rows.append((pname, kname[:90], len(vals), statistics.median(vals), statistics.median(wv[0]) if wv else 0, rd, wt, images))
         with open(os.path.join(dst, "%s_hbm_traffic_%d.csv" % (tag, size)), "w", newline="") as f:
             w = csv.writer(f)
             w.writerow(["calibration", "copy_f4 128 MiB", "FETCH_SIZE_KiB", cf, "factor", fetch_factor, "WRITE_SIZE_KiB", cw, "factor", write_factor])
-            w.writerow(["(per LAUNCH of %d images)" % images])
-            w.writerow(["pass", "kernel", "dispatches", "FETCH_SIZE_median_KiB", "WRITE_SIZE_median_KiB", "read_bytes(corrected)", "write_bytes"])
+            w.writerow(["(per LAUNCH; images per launch in the last column: the inverse row passes C1 / C2 go in chunks of 2 images at 4096^2)"])
+            w.writerow(["pass", "kernel", "dispatches", "FETCH_SIZE_median_KiB", "WRITE_SIZE_median_KiB", "read_bytes(corrected)", "write_bytes", "images_per_launch"])
             for r in rows:
                 w.writerow(r)
         tj["fast/half/%d" % size] = traffic
