@@ -93,10 +93,11 @@ int fdr_plan_dims(const fdr_plan* plan, int* M, int* N, int* mode);
                                       the internal streams, join) as a hipGraph on first use and replays it while the call's
                                       arguments stay the same: for small images, whose batches are bound by the host's
                                       launch rate.  0 (default) = plain launches. */
-#define FDR_OPT_CE_CACHE_MB 4      /* batched fast mode: the inverse row passes C1 + C2 of a group of images are launched over as many
-                                      images at a time as keep the spectra they read TWICE within this many MiB (the chip's
-                                      256 MiB Infinity Cache serves the second read): default 160 -> 2 images per C1 / C2 launch at
-                                      4096^2, the whole group below; 0 = always the whole group.  Same bits either way. */
+#define FDR_OPT_CE_CHUNK_MB 4      /* batched fast mode on two or more streams: the inverse row passes C1 + C2 of a group of images are
+                                      launched in chunks of the group -- as many images as make up at least this many MiB of spectrum
+                                      (default 160: pairs at 4096^2, the whole group below) -- because launches of half the size
+                                      interleave better with the other stream's memory-bound passes; 0 = always the whole group.
+                                      Same bits either way. */
 int fdr_plan_set_option(fdr_plan* plan, int option, long long value);
 
 /* -- PSF generation: utils.hpp:15-24 motionBlurKernel(size, angle) ------------------- */

@@ -29,7 +29,7 @@ NORM_CROPPED = 0
 MAX_PASSES = 16
 OPT_TWO_SWEEP_NORM = 2
 OPT_BATCH_GRAPH = 3
-OPT_CE_CACHE_MB = 4
+OPT_CE_CHUNK_MB = 4
 PHASES = ("alloc", "h2d", "pre", "compute", "d2h", "post")  # the reference Profiler's buckets, fft/fft_gpu.cu:17-57
 BATCH_MAX_DEVICES = 16
 

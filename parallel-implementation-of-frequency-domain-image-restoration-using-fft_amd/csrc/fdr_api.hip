@@ -163,7 +163,7 @@ struct fdr_plan {
     hipEvent_t fork = nullptr;
     size_t ws_elems = 0;  // elements of one work / raw buffer
     bool two_sweep = true;           // FDR_OPT_TWO_SWEEP_NORM: passes C1 + C2 instead of C' + E (fast half-spectrum path)
-    size_t ce_cache_bytes = (size_t)160 << 20;  // FDR_OPT_CE_CACHE_MB: spectra one C1 + C2 launch pair may touch (0 = whole group at once)
+    size_t ce_chunk_bytes = (size_t)160 << 20;  // FDR_OPT_CE_CHUNK_MB: spectrum bytes per C1 + C2 launch pair of a multi-stream batch (0 = whole group)
     // FDR_OPT_BATCH_GRAPH: the launches of one fdr_wiener_batch_f32_dev call (fork, every pass of every group on the
     // internal streams, join) captured once as a hipGraph and replayed while the call's arguments stay the same
     struct GraphKey {
@@ -765,9 +765,9 @@ int fdr_plan_set_option(fdr_plan* p, int option, long long value) {
             if (value != 0 && value != 1) return fail(FDR_ERR_ARG, "fdr_plan_set_option: FDR_OPT_BATCH_GRAPH takes 0 or 1");
             p->batch_graph = value != 0;
             return FDR_OK;
-        case FDR_OPT_CE_CACHE_MB:
-            if (value < 0 || value > (1 << 20)) return fail(FDR_ERR_ARG, "fdr_plan_set_option: FDR_OPT_CE_CACHE_MB takes 0 .. 1048576");
-            p->ce_cache_bytes = (size_t)value << 20;
+        case FDR_OPT_CE_CHUNK_MB:
+            if (value < 0 || value > (1 << 20)) return fail(FDR_ERR_ARG, "fdr_plan_set_option: FDR_OPT_CE_CHUNK_MB takes 0 .. 1048576");
+            p->ce_chunk_bytes = (size_t)value << 20;
             return FDR_OK;
         case FDR_OPT_TWO_SWEEP_NORM:
             if (value != 0 && value != 1) return fail(FDR_ERR_ARG, "fdr_plan_set_option: FDR_OPT_TWO_SWEEP_NORM takes 0 or 1");
@@ -915,7 +915,7 @@ int fdr_wiener_batch_f32_dev(fdr_plan* p, const float* d_imgs, size_t img_pitch,
     // Not with per-kernel profiling (host-side event pairs).
     if (p->batch_graph && p->panel && !p->timer.enabled) {
         const fdr_plan::GraphKey key{d_imgs, d_out, img_pitch, out_pitch, count, rows, cols, stride, out_stride, norm_area, p->nstreams, p->group,
-                                     p->two_sweep, p->K, p->ce_cache_bytes};
+                                     p->two_sweep, p->K, p->ce_chunk_bytes};
         if (!(p->graph_exec && key == p->graph_key)) {
             if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
             if (!p->cap_stream) FDR_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
@@ -967,17 +967,20 @@ int batch_enqueue(fdr_plan* p, const float* d_imgs, size_t img_pitch, int count,
             for (int k = 0; k < n; ++k) { ins[k] = d_imgs + (size_t)(i0 + k) * img_pitch; outs[k] = d_out + (size_t)(i0 + k) * out_pitch; }
             rc = panel_stage_A_batch(p, ws, n, ins, rows, cols, stride, s);
             if (rc == FDR_OK) rc = panel_stage_B(p, ws, n, s);
-            // The two inverse row passes (C1: extremes, C2: the same transform again, normalised) read the spectrum twice.
-            // Launched over all n images of a group at 4096^2 they touch 4 x 64 MiB between the two reads of a line -- more
-            // than the 256 MiB Infinity Cache keeps -- so they go in chunks whose spectra stay inside it (p->ce_cache_bytes,
-            // FDR_OPT_CE_CACHE_MB): 2 images at 4096^2 (89.2 -> 87.9 us per image, 2 streams x 4), everything at once at 2048^2
-            // and below (16 MiB per image: one chunk; smaller launches only cost there: 21.3 -> 25.3 us), and no split where one
-            // image's spectrum alone exceeds the budget (8192^2: 256 MiB, measured no difference).
+            // The two inverse row passes (C1: extremes; C2: the same transform again, normalised) go in CHUNKS of the group
+            // when the batch alternates over two or more streams: C1 is the pass with exposed compute, and in launches of half
+            // the size it interleaves better with the memory-bound passes of the other stream's group.  Measured at 4096^2,
+            // 2 streams x 4 images, alternating runs on one box: chunks of 4 / 2 / 1 images 89.1 / 87.9 / 87.5 us per image;
+            // with ONE stream the chunks only make the launches smaller (91.5 -> 93.1 us), at 2048^2 too (21.3 -> 25.3 us), and
+            // passes A / B' lose in chunks at any size (89.3 -> 91.1 / 93.4 us).  Hence: >= 2 streams, and a chunk holds at least
+            // ce_chunk_bytes of spectrum (FDR_OPT_CE_CHUNK_MB, default 160 MiB: pairs at 4096^2, the whole group below, no
+            // split where one image alone is larger).  (Not an Infinity-Cache effect, although the 256 MiB suggest it: the
+            // passes' own durations get LONGER in chunks, C1 14.0 -> 16.4 us per image; the gain is in the overlap.)
             int chunk = n;
-            {
+            if (ns > 1) {
                 const size_t spec_bytes = p->ws_elems * sizeof(float2);
-                if (p->ce_cache_bytes > 0 && spec_bytes <= p->ce_cache_bytes) {
-                    const size_t c = p->ce_cache_bytes / spec_bytes;
+                if (p->ce_chunk_bytes > 0 && spec_bytes <= p->ce_chunk_bytes) {
+                    const size_t c = p->ce_chunk_bytes / spec_bytes;
                     if (c < (size_t)n) chunk = (int)c;
                 }
             }

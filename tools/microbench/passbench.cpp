@@ -1,7 +1,7 @@
 // passbench -- torch-free timing of the restoration passes through the C ABI of a libfdr build chosen at run time
 // (dlopen), so that one GPU call can compare several builds and sizes without paying a Python / torch start-up each.
 //
-//   passbench <libfdr.so> <size> [batch=8] [steps=10] [streams=1] [group=1] [mode=1] [flags=0] [two_sweep=-1 (library default)] [graph=0]
+//   passbench <libfdr.so> <size> [batch=8] [steps=10] [streams=1] [group=1] [mode=1] [flags=0] [two_sweep=-1 (library default)] [graph=0] [ce_chunk_mb=-1]
 //
 // Prints: per-pass mean device time (hipEvent pairs, one stream, un-overlapped) with the fraction of the 8 TB/s HBM
 // peak its algorithmic bytes give, then the batched throughput with the requested streams / group (median of 5).
@@ -59,6 +59,7 @@ int main(int argc, char** argv) {
     const unsigned flags = argc > 8 ? (unsigned)std::strtoul(argv[8], nullptr, 0) : 0u;
     const int two_sweep = argc > 9 ? std::atoi(argv[9]) : -1;
     const int graph = argc > 10 ? std::atoi(argv[10]) : 0;
+    const int ce_chunk_mb = argc > 11 ? std::atoi(argv[11]) : -1;  // FDR_OPT_CE_CHUNK_MB (-1: library default)
     void* h = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
     if (!h) { std::printf("dlopen %s: %s\n", libpath, dlerror()); return 1; }
     Api api;
@@ -77,6 +78,7 @@ int main(int argc, char** argv) {
     fdr_plan* plan = nullptr;
     FCK(api.plan_create(0, S, S, mode, flags, &plan));
     if (two_sweep >= 0) FCK(api.set_option(plan, 2 /* FDR_OPT_TWO_SWEEP_NORM */, two_sweep));
+    if (ce_chunk_mb >= 0) FCK(api.set_option(plan, 4 /* FDR_OPT_CE_CHUNK_MB */, ce_chunk_mb));
     FCK(api.set_psf_motion(plan, 50, 30.0, 0.01f, st));
     FCK(api.synth(0, 0x5EED0003ull, 0, P * B, d_in, st));
     CK(hipStreamSynchronize(st));
@@ -95,7 +97,7 @@ int main(int argc, char** argv) {
     FCK(api.pass_times(plan, &n, ms, names, launches));
     FCK(api.profile(plan, 0));
     double sum_us = 0;
-    std::printf("== %s  size %d  batch %d  steps %d  mode %d flags %u two_sweep %d\n", libpath, S, B, steps, mode, flags, two_sweep);
+    std::printf("== %s  size %d  batch %d  steps %d  mode %d flags %u two_sweep %d ce_chunk_mb %d\n", libpath, S, B, steps, mode, flags, two_sweep, ce_chunk_mb);
     for (int i = 0; i < n; ++i) {
         std::string nm = names[i];
         int nimg = 1;
