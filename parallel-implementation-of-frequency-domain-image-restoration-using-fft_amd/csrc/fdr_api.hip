@@ -652,10 +652,6 @@ static int plan_create_impl(fdr_plan* p, int device, int M, int N, int mode, uns
     size_t P = (size_t)M * N;
     if (p->panel) {  // panel-major buffers: panels of 4 columns, PS elements apart (not a power of two: channel skew)
         p->pstride = (size_t)M * 4 + 16;
-        if (const char* e = std::getenv("FDR_DEBUG_PSTRIDE_PAD")) {  // experiment: other skews (elements, multiple of 4)
-            const long pad = std::atol(e);
-            if (pad >= 0 && pad % 4 == 0) p->pstride = (size_t)M * 4 + (size_t)pad;
-        }
         p->half = N >= 32 && (flags & FDR_FLAG_FULL_SPECTRUM) == 0;
         p->npanels = p->half ? N / 8 : N / 4;
         P = (size_t)p->npanels * p->pstride;

@@ -560,20 +560,6 @@ struct FftCore {
         }
     }
 
-    // The same with a hook called once, right before the LAST exchange (the point from which only one LDS round trip and
-    // one step of butterflies are left): pass B' requests its first filter pieces there.
-    template <int J, int SEQ0, bool INV, class Hook>
-    static __device__ __forceinline__ void steps_from_hook(float2 (&v)[B][V], float2* lds, const float2* __restrict__ tw,
-                                                           const Bases& bs, int tid, Hook& hook) {
-        butterflies<J, INV>(v, tw, bs, tid);
-        if constexpr (J + 1 < S) {
-            if constexpr (J + 2 == S) hook();
-            if constexpr (SWAP0 && J == 0) exchange_swap(v);
-            else exchange<J, SEQ0>(v, lds, tid);
-            steps_from_hook<J + 1, SEQ0, INV>(v, lds, tw, bs, tid, hook);
-        }
-    }
-
     // Last-step result order -> first-step operand order, for chaining a second transform (forward . filter . inverse).
     // Both are the SAME thread's values: element indices are tid + T j, j < V, with j = u + (q << (LOGV - lr)) in either
     // order, so the change of order is a renaming of registers -- no exchange.
@@ -604,17 +590,6 @@ struct FftCore {
         (void)lds; (void)tw; (void)bs; (void)tid; (void)v;
 #else
         steps_from<0, SEQ0, INV>(v, lds, tw, bs, tid);
-#endif
-    }
-    template <int SEQ0, bool INV, class Hook>
-    static __device__ __forceinline__ void run_hook(float2 (&v)[B][V], float2* lds, const float2* __restrict__ tw, const Bases& bs,
-                                                    int tid, Hook&& hook) {
-#ifdef FDR_DEBUG_SKIP_FFT
-        (void)lds; (void)tw; (void)bs; (void)tid; (void)v;
-        hook();
-#else
-        static_assert(S >= 2, "a last exchange exists");
-        steps_from_hook<0, SEQ0, INV>(v, lds, tw, bs, tid, hook);
 #endif
     }
 };

@@ -1394,15 +1394,6 @@ __device__ __forceinline__ void tile_store(float2* __restrict__ ubase, unsigned 
 // and treats them as landed afterwards.  Used right before the tile's stores are issued: vmcnt counts loads and
 // stores in issue order, so a wait for the spectrum prefetch placed after the stores (where the values are first
 // used) would also wait for the stores to drain -- ~5 us per tile that the next forward transform should hide.
-template <class Core>
-__device__ __forceinline__ void landed16(const float2 (&d)[4][16]) {
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int s = 0; s < 16; s += 4)
-            asm volatile("" ::"v"(d[b][s].x), "v"(d[b][s].y), "v"(d[b][s + 1].x), "v"(d[b][s + 1].y), "v"(d[b][s + 2].x),
-                         "v"(d[b][s + 2].y), "v"(d[b][s + 3].x), "v"(d[b][s + 3].y));
-}
 __device__ __forceinline__ void landed(const float2 (&d)[4][8]) {
 #pragma unroll
     for (int b = 0; b < 4; ++b)
@@ -1532,9 +1523,6 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::PIPE_WAV
 #ifndef FDR_COLS12_PACKED
 #define FDR_COLS12_PACKED 1
 #endif
-#ifndef FDR_WEARLY
-#define FDR_WEARLY 1
-#endif
 #ifndef FDR_PARK_BASES
 #define FDR_PARK_BASES 1  // 8192-point column pass: twiddle bases parked in LDS across the filter phase (A/B builds: 0)
 #endif
@@ -1597,31 +1585,7 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
     // 8192^2 192.7 / 186.3 / 193.9 / 201.5 us per image at 0 / 7 / 14 / 20 us: the CUs are not in lockstep to begin with.)
     float2 v[4][V];
     tile_load<Core, false>(data, loff, 1u, v);
-    // W in pieces of PC slots (8 VGPRs per slot), two pieces in flight.  (Measured: requesting the first pieces before the
-    // forward transform costs 27 spilled registers and 5 us; the compiler barriers keep hipcc from hoisting all 32 loads to
-    // the top.)  FDR_WEARLY: the first two pieces are requested right before the forward transform's LAST exchange, so that
-    // their latency runs behind that LDS round trip and the last step's butterflies.
-    constexpr int PC = FDR_WPIECE;
-    auto wload = [&](int h, float2 (&w)[PC][4]) {
-#pragma unroll
-        for (int i = 0; i < PC; ++i) {
-            const int s = PC * h + i, u = s / Core::RHOL, q = s % Core::RHOL;
-            const unsigned uoff = (unsigned)(((q << Core::LOGOUT) + u * Core::T) * 4);
-            const gchar* ub = uniform_gptr(tfilt + uoff);
-            FDR_GLOAD32(ub, loff * 8u, w[i][0], w[i][1], w[i][2], w[i][3]);
-        }
-    };
-    float2 wa[PC][4], wb[PC][4];
-#if FDR_WEARLY
-    Core::template run_hook<0, false>(v, grp_lds, tw_fwd, bases, tid, [&] {
-        asm volatile("" ::: "memory");
-        wload(0, wa);
-        if constexpr (FDR_WEARLY >= 2) wload(1, wb);
-        asm volatile("" ::: "memory");
-    });
-#else
     Core::template run<0, false>(v, grp_lds, tw_fwd, bases, tid);
-#endif
 
     const bool packed_tile = packed0 && tl == 0;  // uniform per workgroup
     constexpr int SEQ = Core::SLOTS;
@@ -1670,6 +1634,19 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
     }
     {
         const bool col0_done = packed_tile && g == 0;
+        // W in pieces of PC slots, the next piece requested before the current one is used.  (Measured: requesting the
+        // first pieces before the forward transform costs 27 spilled registers and 5 us; the compiler barriers keep
+        // hipcc from hoisting all 32 loads to the top.)
+        constexpr int PC = FDR_WPIECE;  // slots per piece: 8 VGPRs per slot, two pieces in flight
+        auto wload = [&](int h, float2 (&w)[PC][4]) {
+#pragma unroll
+            for (int i = 0; i < PC; ++i) {
+                const int s = PC * h + i, u = s / Core::RHOL, q = s % Core::RHOL;
+                const unsigned uoff = (unsigned)(((q << Core::LOGOUT) + u * Core::T) * 4);
+                const gchar* ub = uniform_gptr(tfilt + uoff);
+                FDR_GLOAD32(ub, loff * 8u, w[i][0], w[i][1], w[i][2], w[i][3]);
+            }
+        };
         auto wmul = [&](int h, const float2 (&w)[PC][4]) {
 #pragma unroll
             for (int i = 0; i < PC; ++i) {
@@ -1680,18 +1657,7 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
                 v[3][s] = cmul_fma(v[3][s], w[i][3]);
             }
         };
-#if FDR_WEARLY
-        if constexpr (FDR_WEARLY < 2) { asm volatile("" ::: "memory"); wload(1, wb); }
-#pragma unroll
-        for (int h = 0; h < V / PC; h += 2) {
-            wmul(h, wa);
-            asm volatile("" ::: "memory");
-            if (h + 2 < V / PC) wload(h + 2, wa);
-            wmul(h + 1, wb);
-            asm volatile("" ::: "memory");
-            if (h + 3 < V / PC) wload(h + 3, wb);
-        }
-#else
+        float2 wa[PC][4], wb[PC][4];
         wload(0, wa);
 #pragma unroll
         for (int h = 0; h < V / PC; h += 2) {
@@ -1702,7 +1668,6 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
             if (h + 2 < V / PC) wload(h + 2, wa);
             wmul(h + 1, wb);
         }
-#endif
     }
     {
         // opaque copy of the thread index: the inverse transform's LDS addresses equal the forward transform's, and as
@@ -1720,153 +1685,6 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
         }
     }
     if (active) tile_store<Core>(data, loff, v);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Pass B', PERSISTENT (4096-point columns, 2 / 4 / 8 images per launch): ONE 256-thread workgroup per CU at one wave per
-// SIMD, which may then use all 512 registers of a lane -- the 256 VGPRs for the tile being transformed (128) and the
-// transforms' temporaries, and 128 of the 256 AGPRs for a prefetch set that holds, in turn, the WHOLE filter tile (requested
-// before the forward transform, used behind it) and the NEXT tile of the same image (requested behind the filter product,
-// i.e. in flight during the inverse transform; the tile's stores then drain behind the next forward transform).  128 KB per
-// CU are in flight nearly all the time and no load is waited for except the very first; the one-shot kernel above holds its
-// tile from the first load to the last store and leaves the overlap of memory and transform phases to two co-resident
-// workgroups.
-// hipcc does not allocate load results to AGPRs by itself (it spills them to scratch right behind the loads, and every
-// scratch access drains the in-order vmcnt queue), so the prefetches are `global_load_dwordx4 a[..]` in inline asm with
-// hand-placed `s_waitcnt vmcnt(0)` before the first use (whatever else the compiler queued in between is then complete
-// as well, so the scheme does not depend on counting); the twiddle bases are hoisted (PolicyFast), so no vector-memory load
-// of the compiler's sits inside the transforms.
-// Tiles of one image per workgroup (image = the workgroup's slot on its XCD, so the images that share a slice of W stay
-// neighbours on one L2).
-// ---------------------------------------------------------------------------------------------
-#ifndef FDR_COLS_PERS16
-#define FDR_COLS_PERS16 0
-#endif
-
-// 32 bytes at (uniform base) + (32-bit lane byte offset) into two AGPR quads; completion is NOT tracked by the compiler
-__device__ __forceinline__ void agload32(const gchar* ub, unsigned lane_bytes, nfloat4& lo, nfloat4& hi) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(lo) : "v"(lane_bytes), "s"(ub) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=a"(hi) : "v"(lane_bytes), "s"(ub) : "memory");
-}
-// every later read of the 32 quads is ordered behind this point (volatile asms keep their order; each quad passes through one)
-__device__ __forceinline__ void agtie(nfloat4 (&x)[16][2]) {
-#pragma unroll
-    for (int s = 0; s < 16; s += 4)
-        asm volatile("" : "+a"(x[s][0]), "+a"(x[s][1]), "+a"(x[s + 1][0]), "+a"(x[s + 1][1]), "+a"(x[s + 2][0]), "+a"(x[s + 2][1]),
-                     "+a"(x[s + 3][0]), "+a"(x[s + 3][1]));
-}
-
-template <int LOGM>
-__global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 1) void fft_cols_panel_pers16_kernel(
-    const PanelBatch pb, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const unsigned pstride,
-    const int ntiles, const int packed0, const int img_shift, const int tile_step) {
-    using St = Steps<LOGM, 4>;
-    constexpr int T = St::T, M = St::L, V = 16;
-    static_assert(Panel16Geom<LOGM>::G == 1, "one panel per workgroup");
-    using Core = FftCore<LOGM, 4, 2, PolicyFast, 4, (St::lr(0) == 1 && T >= 64 && FDR_SWAP0)>;
-    static_assert(Core::NU0 * Core::RHO0 == V && Core::NUL * Core::RHOL == V, "16 values per thread");
-    __shared__ float2 lds[2 * St::BUF];
-    const int tid = Core::thread_index((int)threadIdx.x);
-    // workgroup b of the flat one-shot grid handled (image, tile) = (j mod images, (j div images) * 8 + b mod 8), j = b div 8;
-    // this workgroup takes b = blockIdx.x + k gridDim.x, k = 0, 1, ... with gridDim.x a multiple of 8 * images: always the
-    // same image, tiles tile_step = gridDim.x / images apart
-    const int b = (int)blockIdx.x, j = b >> 3;
-    const int img = j & ((1 << img_shift) - 1);
-    int tl = ((j >> img_shift) << 3) | (b & 7);
-    if (tl >= ntiles) return;  // uniform over the workgroup
-    float2* __restrict__ image = pick_image(pb.data, img);
-    const unsigned loff = (unsigned)tid * 4u;
-    const unsigned lbytes = loff * 8u;
-
-    typename Core::Bases bases;
-    Core::init_bases(bases, tw_fwd, tid);
-
-    float2 cur[4][V];
-    tile_load<Core, false>(image + (size_t)tl * pstride, loff, 1u, cur);
-    landed16<Core>(cur);  // the compiler's own waits for these loads stay out of the loop
-    while (true) {
-        const int tn = tl + tile_step;
-        const bool more = tn < ntiles;
-        float2* __restrict__ data = image + (size_t)tl * pstride;
-        const float2* __restrict__ tfilt = filt + (size_t)tl * pstride;
-        // (the prefetch stays unconditional: without a next tile every lane re-reads the first 32 bytes of the filter)
-        const float2* __restrict__ ndata = more ? image + (size_t)tn * pstride : filt;
-        const unsigned nscale = more ? 1u : 0u;
-
-        nfloat4 wq[V][2];
-#pragma unroll
-        for (int s = 0; s < V; ++s) {  // filter, last-step (result) order: in flight behind the forward transform
-            const int u = s / Core::RHOL, q = s % Core::RHOL;
-            const unsigned uoff = (unsigned)(((q << Core::LOGOUT) + u * Core::T) * 4);
-            agload32(uniform_gptr(tfilt + uoff), lbytes, wq[s][0], wq[s][1]);
-        }
-
-        Core::template run<0, false>(cur, lds, tw_fwd, bases, tid);
-
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the filter has landed (and the previous tile's stores have drained)
-        agtie(wq);
-        const bool packed_tile = packed0 && tl == 0;  // uniform per workgroup
-        constexpr int SEQ = Core::SLOTS;
-        if (packed_tile) {  // column 0 of panel 0 (packed DC + i Nyquist), as in the one-shot kernel; its filter slots are wq[.][0].xy
-            float2* bufc = lds + (SEQ & 1) * St::BUF;
-            float2* bufs = lds + ((SEQ + 1) & 1) * St::BUF;
-            __syncthreads();
-            FDR_JITTER(4031);
-#pragma unroll
-            for (int s = 0; s < V; ++s) {
-                const int k = Core::out_index(tid, s / Core::RHOL, s % Core::RHOL);
-                bufc[k] = cur[0][s];
-                bufs[k] = make_float2(wq[s][0].x, wq[s][0].y);
-            }
-            __syncthreads();
-            FDR_JITTER(4032);
-#pragma unroll
-            for (int s = 0; s < V; ++s) {
-                const int k = Core::out_index(tid, s / Core::RHOL, s % Core::RHOL);
-                const int km = (M - k) & (M - 1);
-                const float2 c = cur[0][s], cm = bufc[km], sm = bufs[km], sl_s = make_float2(wq[s][0].x, wq[s][0].y);
-                const float2 f0 = make_float2(0.5f * (c.x + cm.x), 0.5f * (c.y - cm.y));
-                const float2 fn = make_float2(0.5f * (c.y + cm.y), 0.5f * (cm.x - c.x));
-                float2 a0, an;
-                if (k == 0 || k == M / 2) { a0 = make_float2(sl_s.x, 0.f); an = make_float2(sl_s.y, 0.f); }
-                else if (k < M / 2) { a0 = sl_s; an = sm; }
-                else { a0 = make_float2(sm.x, -sm.y); an = make_float2(sl_s.x, -sl_s.y); }
-                const float2 z0 = cmul_fma(f0, a0), zn = cmul_fma(fn, an);
-                cur[0][s] = make_float2(z0.x - zn.y, z0.y + zn.x);
-            }
-            __syncthreads();  // both buffers were read above
-        }
-#pragma unroll
-        for (int s = 0; s < V; ++s) {
-            cur[0][s] = cmul_fma(cur[0][s], packed_tile ? make_float2(1.f, 0.f) : make_float2(wq[s][0].x, wq[s][0].y));
-            cur[1][s] = cmul_fma(cur[1][s], make_float2(wq[s][0].z, wq[s][0].w));
-            cur[2][s] = cmul_fma(cur[2][s], make_float2(wq[s][1].x, wq[s][1].y));
-            cur[3][s] = cmul_fma(cur[3][s], make_float2(wq[s][1].z, wq[s][1].w));
-        }
-        nfloat4 nq[V][2];  // (the filter's registers are free again)
-#pragma unroll
-        for (int s = 0; s < V; ++s) {  // next tile, first-step (operand) order: in flight behind the inverse transform
-            const int u = s / Core::RHO0, q = s % Core::RHO0;
-            const unsigned uoff = (unsigned)(((q << Core::LOGR0) + u * Core::T) * 4) * nscale;
-            agload32(uniform_gptr(ndata + uoff), lbytes * nscale, nq[s][0], nq[s][1]);
-        }
-        Core::permute_out_to_in(cur);
-        Core::template run<SEQ, true>(cur, lds, tw_fwd, bases, tid);
-
-        // vmcnt counts loads and stores in issue order: the prefetch is waited for BEFORE the stores are queued
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        agtie(nq);
-        tile_store<Core>(data, loff, cur);
-        if (!more) break;
-#pragma unroll
-        for (int s = 0; s < V; ++s) {
-            cur[0][s] = make_float2(nq[s][0].x, nq[s][0].y);
-            cur[1][s] = make_float2(nq[s][0].z, nq[s][0].w);
-            cur[2][s] = make_float2(nq[s][1].x, nq[s][1].y);
-            cur[3][s] = make_float2(nq[s][1].z, nq[s][1].w);
-        }
-        tl = tn;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2029,16 +1847,6 @@ static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const floa
             using G16 = Panel16Geom<LOGM>;
             const int nt16 = (npanels + G16::G - 1) / G16::G;
             const int ishift = FDR_SHARE_W && (nt16 % 8 == 0) ? (pb.nimg == 2 ? 1 : pb.nimg == 4 ? 2 : pb.nimg == 8 ? 3 : -1) : -1;
-            if constexpr (FDR_COLS_PERS16 && LOGM == 12) {
-                const int unit = 8 * pb.nimg, ncu = a.num_cu > 0 ? a.num_cu : 256;
-                if (ishift >= 0 && ncu >= unit && npanels == nt16) {
-                    int grid = (ncu / unit) * unit;
-                    if (grid > nt16 * pb.nimg) grid = nt16 * pb.nimg;
-                    hipLaunchKernelGGL((fft_cols_panel_pers16_kernel<LOGM>), dim3(grid), dim3(G16::THREADS), 0, s, pb, a.filt, tw, (unsigned)ps, nt16,
-                                       a.packed0, ishift, grid / pb.nimg);
-                    return hipGetLastError();
-                }
-            }
             const dim3 grid16 = ishift < 0 ? dim3(nt16, pb.nimg) : dim3(nt16 * pb.nimg);
             hipLaunchKernelGGL((fft_cols_panel_fused16_kernel<LOGM>), grid16, dim3(G16::THREADS), 0, s, pb, a.filt, tw,
                                (unsigned)ps, npanels, nt16, a.packed0, ishift);
