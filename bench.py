@@ -305,6 +305,27 @@ def main():
     passes = plan.pass_times()
     plan.profile(False)
 
+    # ---- what a plain streaming kernel reaches on THIS device, for context next to the nominal peak: an out-of-place
+    # elementwise pass (read 4 B + write 4 B per element) over the floats of one launch group, torch's own kernel ----
+    stream_ref = None
+    if rank == 0:
+        try:
+            n_el = P * max(1, min(args.group, 8))
+            src = torch.empty(n_el, dtype=torch.float32, device=dev).fill_(1.0)
+            dst = torch.empty_like(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(3):
+                torch.mul(src, 1.0, out=dst)
+            e0.record()
+            for _ in range(20):
+                torch.mul(src, 1.0, out=dst)
+            e1.record()
+            torch.cuda.synchronize()
+            stream_ref = 8.0 * n_el * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del src, dst
+        except Exception:
+            stream_ref = None
+
     rc = 0
     if rank == 0:
         images = int(tot[0])
@@ -345,6 +366,13 @@ def main():
                              "frac": round(pipe_gbps / HBM_PEAK_GBPS, 4),
                              "c2c_56_Bpx_would_need_GBps": round(PIPELINE_BYTES[(args.mode, "full")] * P * images / elapsed / 1e9, 1)},
             }
+            if stream_ref:
+                roofline["streaming_reference"] = {
+                    "what": "out-of-place elementwise pass (torch.mul, read 4 B + write 4 B per element) over %d x %dx%d floats, timed in this "
+                            "process after the timed region: what a plain streaming kernel reaches on this device; context, not the peak"
+                            % (max(1, min(args.group, 8)), S, S),
+                    "GBps": round(stream_ref, 1), "frac_of_peak": round(stream_ref / HBM_PEAK_GBPS, 4),
+                    "kernel_over_reference": round(achieved / stream_ref, 4), "pipeline_over_reference": round(pipe_gbps / stream_ref, 4)}
             tfile = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tfile):
                 try:

@@ -1643,8 +1643,13 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
             for (int i = 0; i < PC; ++i) {
                 const int s = PC * h + i, u = s / Core::RHOL, q = s % Core::RHOL;
                 const unsigned uoff = (unsigned)(((q << Core::LOGOUT) + u * Core::T) * 4);
+#ifdef FDR_DEBUG_SKIP_W  // timing-only builds: pass B' without its filter traffic
+                (void)uoff;
+                w[i][0] = w[i][1] = w[i][2] = w[i][3] = make_float2(1.0f, __uint_as_float(loff) * 0.f);
+#else
                 const gchar* ub = uniform_gptr(tfilt + uoff);
                 FDR_GLOAD32(ub, loff * 8u, w[i][0], w[i][1], w[i][2], w[i][3]);
+#endif
             }
         };
         auto wmul = [&](int h, const float2 (&w)[PC][4]) {
