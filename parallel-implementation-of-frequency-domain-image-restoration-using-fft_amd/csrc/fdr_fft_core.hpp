@@ -599,6 +599,29 @@ struct FftCore {
 // small kernel reduces the partials (deterministic, and no same-address atomics: 65k atomics on
 // two words cost ~0.7 ms on MI355X, 15x the kernel that issued them).
 // ---------------------------------------------------------------------------------------------
+// min / max of three as ONE instruction.  Written as fminf / fmaxf chains hipcc quiets every operand it cannot prove
+// canonical first (`v_max_f32 x, x, x`: transform results that went through LDS, DPP or an asm tie): pass C1's 64 values per
+// lane cost 490 VALU instructions that way, 64 this way -- and that pass is bound by its VALU issue (4 waves per SIMD).
+// NaN handling as v_min_f32 / v_max_f32 in IEEE mode (a quiet NaN operand is ignored, like fminf).
+__device__ __forceinline__ float fdr_min3(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return fminf(a, fminf(b, c));
+#endif
+}
+__device__ __forceinline__ float fdr_max3(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return fmaxf(a, fmaxf(b, c));
+#endif
+}
+
 __device__ __forceinline__ void block_minmax_store(float mn, float mx, float2* __restrict__ part, int index = -1) {
     __shared__ float2 red[16];
 #pragma unroll

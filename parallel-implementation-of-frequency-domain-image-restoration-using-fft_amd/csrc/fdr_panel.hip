@@ -526,27 +526,114 @@ __device__ __forceinline__ void rows4_pack(int tid, const float2 (&y)[4][Core::V
 // fabric a second time (fabric reads of pass C' measured at 1.10x / 1.45x the stored bytes at 4096^2 / 8192^2).
 //   y[row][j], j = u (RHO0/2) + q : stored column in_index(tid, u, q), q < RHO0/2
 // ---------------------------------------------------------------------------------------------
+// How the four rows reach the registers (round 3).  The transform wants lane t to hold COLUMN t & 3 of the four rows of its
+// panel; loaded that way every lane issues four 8-byte loads and a 128-byte line (4 rows x 4 columns of a panel) is requested
+// in sixteen pieces -- `tools/microbench/rmw_bench` (h) / (i): that gather reads a 4096^2 half spectrum at 4.7 TB/s, the same
+// lines requested as ONE 32-byte row of the panel per lane (a quad of lanes = the whole line) at 6.7 TB/s, at any occupancy.
+// So lane t loads ROW t & 3 -- four columns, two 16-byte loads -- and the quad transposes its 4 x 4 block in registers: two
+// rounds of `v_cndmask_b32_dpp` (quad_perm [1,0,3,2], then [2,3,0,1]), 16 VALU instructions per panel and lane, no LDS.
+// Measured (passbench, A/B builds on one box): with the transforms compiled out C1 14.5 -> 11.0 and C2 29.9 -> 24.1 us per
+// 4096^2 image; with them the passes alone do not move (C1 13.3 -> 13.8: four waves per SIMD keep the VALU 60-70 % busy and the
+// transposes are VALU work) but the two-stream batch does, 87.1 -> 86.2 us per image (twice: +1.1 / +1.6 %), because the
+// other stream's passes get the memory system sooner.  8192-point rows (persistent kernels) and rows of 2048 points and
+// fewer: 1-2 % slower -- FDR_ROWS_LOAD32 therefore applies to 4096-point rows only.
+#ifndef FDR_ROWS_LOAD32
+#define FDR_ROWS_LOAD32 1
+#endif
+#ifndef FDR_ROWS_LOAD32_LOG
+#define FDR_ROWS_LOAD32_LOG 12
+#endif
+template <int CTRL>
+__device__ __forceinline__ float2 quad_swap(float2 v) {  // the value the lane CTRL points at holds (a permutation inside every quad)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int x = __builtin_amdgcn_mov_dpp(__float_as_int(v.x), CTRL, 0xF, 0xF, false);  // (every lane is written: no `old` value)
+    const int y = __builtin_amdgcn_mov_dpp(__float_as_int(v.y), CTRL, 0xF, 0xF, false);
+    return make_float2(__int_as_float(x), __int_as_float(y));
+#else
+    return v;
+#endif
+}
+// r[c] = (row l, column c) on lane l of the quad  ->  q[r] = (row r, column l)
+#ifndef FDR_QUAD_ASM
+#define FDR_QUAD_ASM 1
+#endif
+// d = (lane in MASK) ? keep : (value of `from` on the lane quad_perm points at), both halves of two float2: four
+// v_cndmask_b32_dpp (select and cross-lane read in ONE instruction; hipcc emits v_mov_b32_dpp + v_cndmask_b32 for the C form
+// below, twice the VALU work in a pass that is short of VALU issue slots).  s_nop 1: a DPP operand written by the
+// preceding VALU instruction needs two wait states, and the hazard recogniser does not look into inline asm.
+#define FDR_QUAD_SEL(MASK, PERM, d0, d1, from0, from1, keep0, keep1)                                                        \
+    asm("s_nop 1\n\ts_mov_b32 vcc_lo, " MASK "\n\ts_mov_b32 vcc_hi, " MASK "\n\t"                                          \
+        "v_cndmask_b32_dpp %0, %4, %8, vcc quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"                              \
+        "v_cndmask_b32_dpp %1, %5, %9, vcc quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"                              \
+        "v_cndmask_b32_dpp %2, %6, %10, vcc quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"                             \
+        "v_cndmask_b32_dpp %3, %7, %11, vcc quad_perm:" PERM " row_mask:0xf bank_mask:0xf"                                  \
+        : "=&v"(d0.x), "=&v"(d0.y), "=&v"(d1.x), "=&v"(d1.y)                                                               \
+        : "v"(from0.x), "v"(from0.y), "v"(from1.x), "v"(from1.y), "v"(keep0.x), "v"(keep0.y), "v"(keep1.x), "v"(keep1.y)   \
+        : "vcc")
+__device__ __forceinline__ void quad_transpose(int lane, const float2 (&r)[4], float2& q0, float2& q1, float2& q2, float2& q3) {
+#if FDR_QUAD_ASM && defined(__HIP_DEVICE_COMPILE__)
+    (void)lane;  // (the masks below are the physical lane's low bits, which the logical thread index keeps)
+    float2 a00, a01, a10, a11;
+    FDR_QUAD_SEL("0x55555555", "[1,0,3,2]", a00, a10, r[1], r[3], r[0], r[2]);  // even lanes keep columns 0 / 2, odd lanes take the
+    FDR_QUAD_SEL("0xaaaaaaaa", "[1,0,3,2]", a01, a11, r[0], r[2], r[1], r[3]);  // neighbour's 1 / 3 (and the other way round)
+    FDR_QUAD_SEL("0x33333333", "[2,3,0,1]", q0, q1, a10, a11, a00, a01);
+    FDR_QUAD_SEL("0xcccccccc", "[2,3,0,1]", q2, q3, a00, a01, a10, a11);
+#else
+    constexpr int X1 = 0xB1, X2 = 0x4E;  // quad_perm [1,0,3,2] (lane ^ 1), [2,3,0,1] (lane ^ 2)
+    const bool odd = (lane & 1) != 0, hi = (lane & 2) != 0;
+    const float2 s0 = quad_swap<X1>(r[0]), s1 = quad_swap<X1>(r[1]), s2 = quad_swap<X1>(r[2]), s3 = quad_swap<X1>(r[3]);
+    const float2 a00 = odd ? s1 : r[0], a01 = odd ? r[1] : s0;  // column (lane & 1) of rows 2 j, 2 j + 1 (j = lane / 2) ...
+    const float2 a10 = odd ? s3 : r[2], a11 = odd ? r[3] : s2;  // ... and column 2 + (lane & 1)
+    const float2 t00 = quad_swap<X2>(a00), t01 = quad_swap<X2>(a01), t10 = quad_swap<X2>(a10), t11 = quad_swap<X2>(a11);
+    q0 = hi ? t10 : a00; q1 = hi ? t11 : a01;
+    q2 = hi ? a10 : t00; q3 = hi ? a11 : t01;
+#endif
+}
+
 template <int LOGL, class Core>
 __device__ __forceinline__ void rows4_load_direct(const RowArgs& a, int rr, int tid, float2 (&y)[4][Core::V / 2], unsigned scale = 1u) {
     static_assert(Core::RHO0 >= 2 && Core::LOGR0 >= 2, "n = t + q Q with Q a multiple of 4");
     constexpr int HQ = Core::RHO0 / 2;
+    constexpr bool kRowLoads = FDR_ROWS_LOAD32 && LOGL == FDR_ROWS_LOAD32_LOG;
     const unsigned ps = (unsigned)a.pstride * scale;  // scale = 0: every address collapses onto rows 0..3 of panel 0
     rr = (int)((unsigned)rr * scale);
 #pragma unroll
     for (int u = 0; u < Core::NU0; ++u) {
         const unsigned t = (unsigned)(tid + u * Core::T);  // stored column t + q Q -> panel q Q / 4 + t / 4, column t & 3
-        const unsigned off_d = (t >> 2) * ps + (t & 3u) * scale + (unsigned)rr * 4u;
+        // kRowLoads: row rr + (t & 3) of the panel, its 4 columns; else column t & 3 of rows rr .. rr + 3
+        const unsigned off = kRowLoads ? (t >> 2) * ps + ((unsigned)rr + (t & 3u) * scale) * 4u : (t >> 2) * ps + (t & 3u) * scale + (unsigned)rr * 4u;
 #pragma unroll
         for (int q = 0; q < HQ; ++q) {
             const int j = u * HQ + q;
 #ifdef FDR_DEBUG_SKIP_MEM  // timing-only builds
-            y[0][j] = y[1][j] = y[2][j] = y[3][j] = make_float2((float)(off_d + q), 1.0f);
+            y[0][j] = y[1][j] = y[2][j] = y[3][j] = make_float2((float)(off + q), 1.0f);
 #else
-            const float2* p = a.src_c + (size_t)((q << Core::LOGR0) >> 2) * ps + off_d;
-            y[0][j] = p[0]; y[1][j] = p[4]; y[2][j] = p[8]; y[3][j] = p[12];
+            const float2* p = a.src_c + (size_t)((q << Core::LOGR0) >> 2) * ps + off;
+            if constexpr (kRowLoads) {
+                const float4 lo = reinterpret_cast<const float4*>(p)[0], hi = reinterpret_cast<const float4*>(p)[1];
+                y[0][j] = make_float2(lo.x, lo.y); y[1][j] = make_float2(lo.z, lo.w);
+                y[2][j] = make_float2(hi.x, hi.y); y[3][j] = make_float2(hi.z, hi.w);
+            } else {
+                y[0][j] = p[0]; y[1][j] = p[4]; y[2][j] = p[8]; y[3][j] = p[12];
+            }
 #endif
         }
     }
+#ifndef FDR_DEBUG_SKIP_MEM
+    if constexpr (kRowLoads) {  // (every load of the group is requested before the first transpose)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < Core::NU0 * HQ; ++j) {
+            // one panel after the other: left alone hipcc interleaves all the transposes and their temporaries push a
+            // 128-register kernel over the edge (this asm makes panel j's inputs depend on panel j-1's results)
+            if (j > 0)
+                asm volatile("" : "+v"(y[0][j].x), "+v"(y[0][j].y), "+v"(y[1][j].x), "+v"(y[1][j].y), "+v"(y[2][j].x), "+v"(y[2][j].y),
+                             "+v"(y[3][j].x), "+v"(y[3][j].y), "+v"(y[0][j - 1].x), "+v"(y[1][j - 1].y), "+v"(y[2][j - 1].x), "+v"(y[3][j - 1].y));
+            const float2 r[4] = {y[0][j], y[1][j], y[2][j], y[3][j]};
+            quad_transpose(tid, r, y[0][j], y[1][j], y[2][j], y[3][j]);
+        }
+    }
+#endif
 }
 // z[0] = Y_a + i Y_b of rows 0, 1, z[1] of rows 2, 3; grp_lds: the thread group's two exchange buffers.  Barriers inside
 // (every thread of the workgroup must come here); returns with both buffers free again.
@@ -687,8 +774,8 @@ __device__ __forceinline__ void rows4_inv_epilogue(const RowArgs& a, const int r
         if (r0 + 3 < a.mm_rows && a.mm_cols >= L) {  // whole group counted (always, with FDR_NORM_PADDED)
 #pragma unroll
             for (int s = 0; s < V; ++s) {
-                mn = fminf(fminf(mn, z[0][s].x), fminf(z[0][s].y, fminf(z[1][s].x, z[1][s].y)));
-                mx = fmaxf(fmaxf(mx, z[0][s].x), fmaxf(z[0][s].y, fmaxf(z[1][s].x, z[1][s].y)));
+                mn = fdr_min3(fdr_min3(mn, z[0][s].x, z[0][s].y), z[1][s].x, z[1][s].y);
+                mx = fdr_max3(fdr_max3(mx, z[0][s].x, z[0][s].y), z[1][s].x, z[1][s].y);
             }
         } else {
 #pragma unroll

@@ -57,6 +57,45 @@ __global__ __launch_bounds__(256, 2) void tile_kernel(float4* __restrict__ a, fl
     for (int s = 0; s < 16; ++s) { dst[s * 512 + threadIdx.x * 2] = v[2 * s]; dst[s * 512 + threadIdx.x * 2 + 1] = v[2 * s + 1]; }
 }
 
+// the inverse row passes' READ pattern: a 4-row group takes 128 bytes (4 rows x 4 columns) from each of 512 panels, PS elements
+// apart.  gather8: as the product kernels, lane -> (panel, column), four 8-byte loads (the rows).  gather32: lane -> (panel, row),
+// one 32-byte row of the panel per lane (4 lanes = one 128-byte line).
+constexpr int kPS = 4 * 4096 + 16;
+template <int LDSKB>
+__global__ __launch_bounds__(256, 4) void gather8_kernel(const float2* __restrict__ a, float* __restrict__ sink, size_t img_elems) {
+    __shared__ float pad[LDSKB * 256];  // LDSKB KB of LDS per workgroup: 37 -> four workgroups per CU, as the product kernels
+    if (threadIdx.x == 1023) pad[blockIdx.x & 255] = 1.f;
+    const float2* img = a + (size_t)blockIdx.y * img_elems;
+    const unsigned t = threadIdx.x, r0 = blockIdx.x * 4;
+    float2 y[4][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float2* p = img + (size_t)((t >> 2) + 64 * i) * kPS + (t & 3u) + r0 * 4u;
+        y[0][i] = p[0]; y[1][i] = p[4]; y[2][i] = p[8]; y[3][i] = p[12];
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += y[0][i].x + y[1][i].y + y[2][i].x + y[3][i].y;
+    if (acc == 1.2345e-30f) sink[0] = acc;
+}
+template <int LDSKB>
+__global__ __launch_bounds__(256, 4) void gather32_kernel(const float2* __restrict__ a, float* __restrict__ sink, size_t img_elems) {
+    __shared__ float pad[LDSKB * 256];
+    if (threadIdx.x == 1023) pad[blockIdx.x & 255] = 1.f;
+    const float2* img = a + (size_t)blockIdx.y * img_elems;
+    const unsigned t = threadIdx.x, r0 = blockIdx.x * 4;
+    float4 y[8][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float4* p = reinterpret_cast<const float4*>(img + (size_t)((t >> 2) + 64 * i) * kPS + (r0 + (t & 3u)) * 4u);
+        y[i][0] = p[0]; y[i][1] = p[1];
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += y[i][0].x + y[i][0].w + y[i][1].y + y[i][1].z;
+    if (acc == 1.2345e-30f) sink[0] = acc;
+}
+
 int main(int argc, char** argv) {
     const int images = argc > 1 ? std::atoi(argv[1]) : 4, mib = argc > 2 ? std::atoi(argv[2]) : 64, iters = argc > 3 ? std::atoi(argv[3]) : 20;
     const size_t n_img = (size_t)mib * 1024 * 1024 / 16;
@@ -88,5 +127,20 @@ int main(int argc, char** argv) {
     timeit("(e) read only", (double)n_img * 16 * images, [&] { hipLaunchKernelGGL(read_kernel, dim3(8192), dim3(256), 0, 0, a, (float*)b, n_img * images); });
     timeit("(f) read only, ONE image (stays in the Infinity Cache?)", (double)n_img * 16, [&] { hipLaunchKernelGGL(read_kernel, dim3(8192), dim3(256), 0, 0, a, (float*)b, n_img); });
     timeit("(g) copy, ONE image", (double)n_img * 16 * 2, [&] { hipLaunchKernelGGL(copy_kernel, dim3(8192), dim3(256), 0, 0, a, b, n_img); });
+    if (mib == 64 && (size_t)512 * kPS * 8 <= n_img * 16 + (size_t)images * 0) {
+        // (an image of 512 panels x kPS float2 = 64.06 MiB: the images overlap by 64 KiB in this buffer, which only reads care about)
+    }
+    {
+        const size_t img_elems = (size_t)512 * kPS;  // float2 elements per image
+        float2* g; CK(hipMalloc((void**)&g, img_elems * 8 * images)); CK(hipMemset(g, 0, img_elems * 8 * images));
+        const double bytes = (double)1024 * 512 * 128 * images;
+        timeit("(h) row-group gather, 8 B per lane x 4 rows, 7 workgroups per CU", bytes, [&] { hipLaunchKernelGGL(gather8_kernel<1>, dim3(1024, images), dim3(256), 0, 0, g, (float*)b, img_elems); });
+        timeit("(i) row-group gather, 32 B per lane,          7 workgroups per CU", bytes, [&] { hipLaunchKernelGGL(gather32_kernel<1>, dim3(1024, images), dim3(256), 0, 0, g, (float*)b, img_elems); });
+        timeit("(h4) 8 B per lane x 4 rows, FOUR workgroups per CU (pass C1 / C2)", bytes, [&] { hipLaunchKernelGGL(gather8_kernel<37>, dim3(1024, images), dim3(256), 0, 0, g, (float*)b, img_elems); });
+        timeit("(i4) 32 B per lane,         FOUR workgroups per CU", bytes, [&] { hipLaunchKernelGGL(gather32_kernel<37>, dim3(1024, images), dim3(256), 0, 0, g, (float*)b, img_elems); });
+        timeit("(h2) 8 B per lane x 4 rows, TWO workgroups per CU", bytes, [&] { hipLaunchKernelGGL(gather8_kernel<74>, dim3(1024, images), dim3(256), 0, 0, g, (float*)b, img_elems); });
+        timeit("(i2) 32 B per lane,         TWO workgroups per CU", bytes, [&] { hipLaunchKernelGGL(gather32_kernel<74>, dim3(1024, images), dim3(256), 0, 0, g, (float*)b, img_elems); });
+        CK(hipFree(g));
+    }
     return 0;
 }
