@@ -11,6 +11,7 @@
 #     the same with --bcast-filter (rank 0's filter W broadcast to the other rank instead of recomputed)
 #   * BASELINE config 2 as written -- ONE 1024^2 image per step (bench.py --batch 1 --streams 1 --group 1), also 512^2 and
 #     2048^2 -- with the rocprofv3 kernel trace of the 1024^2 run, and passbench's per-pass view of the same
+#   * tools/microbench/rmw_bench: the passes' TRAFFIC alone as plain streaming kernels (what this device gives the bytes)
 #   usage: tools/collect_profiles.sh <tag>
 set -o pipefail
 TAG=${1:-r03}
@@ -45,6 +46,8 @@ PKG="$GRAFT_REPO_ROOT/parallel-implementation-of-frequency-domain-image-restorat
 for S in 256 512 1024 2048; do tools/microbench/passbench $PKG/libfdr.so $S 8 20 1 1 >> $OUT/single_image_passbench.log 2>&1; done
 tools/microbench/passbench $PKG/libfdr.so 4096 24 10 2 4 >> $OUT/passbench_4096.log 2>&1
 tools/microbench/passbench $PKG/libfdr.so 8192 6 6 2 2 >> $OUT/passbench_8192.log 2>&1
+make -s -C tools/microbench rmw_bench
+(timeout -k 5 60 tools/microbench/rmw_bench 4 64 20; timeout -k 5 60 tools/microbench/rmw_bench 2 256 10) > $OUT/rmw_bench.log 2>&1; echo "rmw_bench rc=$?" >> $OUT/status.txt
 (timeout -k 5 60 tools/microbench/seam_bench 256 256 200; timeout -k 5 60 tools/microbench/seam_bench 128 256 200; timeout -k 5 60 tools/microbench/seam_bench 256 512 200) > $OUT/seam_bench.log 2>&1; echo "seam_bench rc=$?" >> $OUT/status.txt
 # BASELINE config 5 on the one GPU (512 x 2048^2, device resident) and config 2's size (1024^2)
 python3 bench.py --size 2048 --total-batch 512 --steps 10 --warmup 2 --repeats 3 > $OUT/config5_one_gpu.log 2>&1; echo "config5_one_gpu rc=$?" >> $OUT/status.txt

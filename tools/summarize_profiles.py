@@ -133,7 +133,7 @@ def main():
             for r in stats:
                 if "fdr::" in r["Name"]:
                     w.writerow(r)
-    for name in ("single_image_passbench.log", "passbench_4096.log", "passbench_8192.log", "seam_bench.log"):
+    for name in ("single_image_passbench.log", "passbench_4096.log", "passbench_8192.log", "seam_bench.log", "rmw_bench.log"):
         pth = os.path.join(src, name)
         if os.path.exists(pth):
             txt = open(pth).read().replace(ROOT + "/", "")
