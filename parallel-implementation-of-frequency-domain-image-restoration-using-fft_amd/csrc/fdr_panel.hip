@@ -61,7 +61,8 @@ namespace fdr {
 // (The FORWARD kernel with one buffer -- pairs separated and stored one after the other, a lane pair writing the 64-byte half
 // of a line that its rows 2b, 2b+1 make up, four workgroups per CU -- was measured too: pass A 25.5 -> 28.5 us per 4096^2 image;
 // half-line stores cost more than the occupancy gains.  The same with the lines of both pairs held in registers (2 x 4 items
-// of 32 bytes per lane) so that the stores stay whole lines: 25.5 -> 25.2 us -- pass A is not bound by its occupancy.  Not kept.)
+// of 32 bytes per lane) so that the stores stay whole lines: 25.5 -> 25.2 us -- pass A is not bound by its occupancy.  Not kept.
+// Non-temporal stores of the spectrum (it is read again by pass B', but four images do not stay in any cache): 24.0 -> 27.0 us.)
 template <int LOGL>
 struct Rows4PackGeom {
     static constexpr int LOGV = (LOGL <= FDR_ROWS_ONE_V16_MAX && LOGL >= FDR_ROWS_ONE_V16_MIN) ? 4 : 3;
