@@ -1671,6 +1671,21 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
     // a CU alternate between memory and LDS phases, was measured: no gain up to 5 us of delay, slower beyond.  Round 3, the
     // same across CUs: every other TILE's first-round workgroup started 7 .. 40 us late -- 4096^2 35.1 / 34.0 / 34.4 / 36.5 us,
     // 8192^2 192.7 / 186.3 / 193.9 / 201.5 us per image at 0 / 7 / 14 / 20 us: the CUs are not in lockstep to begin with.)
+    // (Round 3, built, verified against the tests, measured and not kept -- the code is in the history, commit "Experiments on
+    // pass B'", numbers in DESIGN.md section 5:
+    // (1) a PERSISTENT form, one 256-thread workgroup per CU at one wave per SIMD with the whole filter tile and then the next
+    //     tile prefetched into 128 AGPRs by inline-asm `global_load_dwordx4 a[..]` and hand-placed vmcnt waits -- no spills,
+    //     nothing waited for, but 41.3 against 32.7 us per 4096^2 image: alone on its SIMD a wave exposes every LDS round trip and
+    //     barrier of the two transforms, 20 us per tile against the 16.5 us two co-resident workgroups take per tile between them;
+    // (2) column-pipelined transforms (a transform's LDS round trip behind the next transform's butterflies): +13 % VALU
+    //     instructions, 33.9 against 32.7 us;
+    // (3) the first filter piece requested before the forward transform's LAST exchange: the transform's register peak is
+    //     there, 19 spilled registers, 34.2 against 32.7 us (8192 points: 176.9 against 182.4 us with 23 spilled registers);
+    // (4) the second half of the filter tile by `global_load_lds_dwordx4` into the exchange buffers, idle between the
+    //     transforms, so that all of W is in flight at once (one round trip instead of two, two more barriers): 33.4 against
+    //     32.7 us, 8192 points 186.6 against 179.2 us.
+    // Without its filter (-DFDR_DEBUG_SKIP_W) the pass takes 28.6 us, and `tools/microbench/rmw_bench` moves the pass's
+    // traffic alone -- four 64 MiB images in place plus one shared 64 MiB filter -- in 94-106 us, 24-26.5 us per image.)
     float2 v[4][V];
     tile_load<Core, false>(data, loff, 1u, v);
     Core::template run<0, false>(v, grp_lds, tw_fwd, bases, tid);
