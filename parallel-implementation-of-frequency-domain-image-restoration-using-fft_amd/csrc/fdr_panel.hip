@@ -53,7 +53,7 @@ namespace fdr {
 #define FDR_ROWS_ONE_V16_MIN 12
 #endif
 #ifndef FDR_ROWS_ONE_V16_MAX
-#define FDR_ROWS_ONE_V16_MAX 12
+#define FDR_ROWS_ONE_V16_MAX 13
 #endif
 #ifndef FDR_ROWS_INV_NBUF1_MIN
 #define FDR_ROWS_INV_NBUF1_MIN 12
@@ -72,7 +72,7 @@ struct Rows4PackGeom {
     static constexpr int THREADS = T * G;
     // inverse kernels with ONE exchange buffer: as many workgroups per CU as the LDS admits, registers capped to match
     static constexpr int INV_LDS = G * St::BUF * 8;
-    static constexpr int INV_WG_PER_CU = (LOGL >= FDR_ROWS_INV_NBUF1_MIN && LOGL == 12) ? ((160 * 1024) / INV_LDS > 4 ? 4 : (160 * 1024) / INV_LDS) : 1;
+    static constexpr int INV_WG_PER_CU = (LOGL >= FDR_ROWS_INV_NBUF1_MIN && LOGL >= 12 && LOGV == 4) ? ((160 * 1024) / INV_LDS > 4 ? 4 : (160 * 1024) / INV_LDS) : 1;
     static constexpr int INV_WAVES_PER_SIMD = INV_WG_PER_CU * THREADS / 256 > 0 ? (INV_WG_PER_CU * THREADS / 256 > 8 ? 8 : INV_WG_PER_CU * THREADS / 256) : 1;
 };
 
@@ -262,8 +262,12 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS) void fft_rows4_fwd_pa
 #ifndef FDR_ROWS_PERS_MIN_LOG
 #define FDR_ROWS_PERS_MIN_LOG 13
 #endif
-#ifndef FDR_ROWS_INV_PERS_MIN_LOG  // the same for the inverse passes (C', C1, C2) alone
-#define FDR_ROWS_INV_PERS_MIN_LOG FDR_ROWS_PERS_MIN_LOG
+// The INVERSE passes (C', C1, C2) stopped using it late in round 3: at 8192 points the one-group kernel with 16 values per
+// thread, ONE exchange buffer (two 512-thread workgroups per CU instead of one persistent workgroup) and whole-row loads
+// (FDR_ROWS_LOAD32) beats the persistent kernel -- C1 76.3 -> 65.2, C2 106.3 -> 100.3 us per 8192^2 image, the two-stream batch
+// 426.9 -> 413.7 us per image.  The persistent inverse kernel stays for A/B builds (-DFDR_ROWS_INV_PERS_MIN_LOG=13).
+#ifndef FDR_ROWS_INV_PERS_MIN_LOG
+#define FDR_ROWS_INV_PERS_MIN_LOG 14
 #endif
 template <int LOGL, int LOGV>
 struct RowsPersGeom {
@@ -536,13 +540,17 @@ __device__ __forceinline__ void rows4_pack(int tid, const float2 (&y)[4][Core::V
 // Measured (passbench, A/B builds on one box): with the transforms compiled out C1 14.5 -> 11.0 and C2 29.9 -> 24.1 us per
 // 4096^2 image; with them the passes alone do not move (C1 13.3 -> 13.8: four waves per SIMD keep the VALU 60-70 % busy and the
 // transposes are VALU work) but the two-stream batch does, 87.1 -> 86.2 us per image (twice: +1.1 / +1.6 %), because the
-// other stream's passes get the memory system sooner.  8192-point rows (persistent kernels) and rows of 2048 points and
-// fewer: 1-2 % slower -- FDR_ROWS_LOAD32 therefore applies to 4096-point rows only.
+// other stream's passes get the memory system sooner.  Rows of 2048 points and fewer: 1-2 % slower, so FDR_ROWS_LOAD32 applies
+// to 4096- and 8192-point rows (FDR_ROWS_LOAD32_LOG .. _MAX); at 8192 points it is what lets the one-group kernel fit 128
+// registers (the serialised transposes bound the live set; the 8-byte gathers spilled 13-22 registers there).
 #ifndef FDR_ROWS_LOAD32
 #define FDR_ROWS_LOAD32 1
 #endif
 #ifndef FDR_ROWS_LOAD32_LOG
 #define FDR_ROWS_LOAD32_LOG 12
+#endif
+#ifndef FDR_ROWS_LOAD32_LOG_MAX
+#define FDR_ROWS_LOAD32_LOG_MAX 13
 #endif
 template <int CTRL>
 __device__ __forceinline__ float2 quad_swap(float2 v) {  // the value the lane CTRL points at holds (a permutation inside every quad)
@@ -595,7 +603,7 @@ template <int LOGL, class Core>
 __device__ __forceinline__ void rows4_load_direct(const RowArgs& a, int rr, int tid, float2 (&y)[4][Core::V / 2], unsigned scale = 1u) {
     static_assert(Core::RHO0 >= 2 && Core::LOGR0 >= 2, "n = t + q Q with Q a multiple of 4");
     constexpr int HQ = Core::RHO0 / 2;
-    constexpr bool kRowLoads = FDR_ROWS_LOAD32 && LOGL == FDR_ROWS_LOAD32_LOG;
+    constexpr bool kRowLoads = FDR_ROWS_LOAD32 && LOGL >= FDR_ROWS_LOAD32_LOG && LOGL <= FDR_ROWS_LOAD32_LOG_MAX;
     const unsigned ps = (unsigned)a.pstride * scale;  // scale = 0: every address collapses onto rows 0..3 of panel 0
     rr = (int)((unsigned)rr * scale);
 #pragma unroll
