@@ -56,23 +56,30 @@ namespace fdr {
 #define FDR_ROWS_ONE_V16_MAX 13
 #endif
 #ifndef FDR_ROWS_INV_NBUF1_MIN
-#define FDR_ROWS_INV_NBUF1_MIN 12
+#define FDR_ROWS_INV_NBUF1_MIN 10  // (wherever the inverse kernels hold 16 values per thread)
 #endif
 // (The FORWARD kernel with one buffer -- pairs separated and stored one after the other, a lane pair writing the 64-byte half
 // of a line that its rows 2b, 2b+1 make up, four workgroups per CU -- was measured too: pass A 25.5 -> 28.5 us per 4096^2 image;
 // half-line stores cost more than the occupancy gains.  The same with the lines of both pairs held in registers (2 x 4 items
 // of 32 bytes per lane) so that the stores stay whole lines: 25.5 -> 25.2 us -- pass A is not bound by its occupancy.  Not kept.
 // Non-temporal stores of the spectrum (it is read again by pass B', but four images do not stay in any cache): 24.0 -> 27.0 us.)
-template <int LOGL>
+// The inverse kernels have their own lower bound, FDR_ROWS_INV_V16_MIN = 2048 points: with ONE exchange buffer the 16-value form
+// keeps four workgroups per CU there too -- 2048^2 in launches of 4: C2 6.65 -> 5.94, C1 5.27 -> 5.08 us per image, the two-stream
+// batch 20.89 -> 20.47 us per image (config 5's size; the forward kernel with 16 values at 2048 points: 7.9 -> 8.2 us, not
+// taken); at 1024 points the 16-value inverse kernels are slower (C2 1.83 -> 2.05 us per image in launches of 8).
+#ifndef FDR_ROWS_INV_V16_MIN
+#define FDR_ROWS_INV_V16_MIN 11
+#endif
+template <int LOGL, bool INV = false>
 struct Rows4PackGeom {
-    static constexpr int LOGV = (LOGL <= FDR_ROWS_ONE_V16_MAX && LOGL >= FDR_ROWS_ONE_V16_MIN) ? 4 : 3;
+    static constexpr int LOGV = (LOGL <= FDR_ROWS_ONE_V16_MAX && LOGL >= (INV ? FDR_ROWS_INV_V16_MIN : FDR_ROWS_ONE_V16_MIN)) ? 4 : 3;
     using St = Steps<LOGL, LOGV>;
     static constexpr int T = St::T;
     static constexpr int G = T >= 256 ? 1 : 256 / T;
     static constexpr int THREADS = T * G;
     // inverse kernels with ONE exchange buffer: as many workgroups per CU as the LDS admits, registers capped to match
     static constexpr int INV_LDS = G * St::BUF * 8;
-    static constexpr int INV_WG_PER_CU = (LOGL >= FDR_ROWS_INV_NBUF1_MIN && LOGL >= 12 && LOGV == 4) ? ((160 * 1024) / INV_LDS > 4 ? 4 : (160 * 1024) / INV_LDS) : 1;
+    static constexpr int INV_WG_PER_CU = (INV && LOGL >= FDR_ROWS_INV_NBUF1_MIN && LOGV == 4) ? ((160 * 1024) / INV_LDS > 4 ? 4 : (160 * 1024) / INV_LDS) : 1;
     static constexpr int INV_WAVES_PER_SIMD = INV_WG_PER_CU * THREADS / 256 > 0 ? (INV_WG_PER_CU * THREADS / 256 > 8 ? 8 : INV_WG_PER_CU * THREADS / 256) : 1;
 };
 
@@ -808,7 +815,7 @@ __device__ __forceinline__ void rows4_inv_epilogue(const RowArgs& a, const int r
 // HALF: the row spectra hold columns 0 .. N/2-1 only, column 0 packed as Y[m,0] + i Y[m,N/2] (see the forward
 // kernel); the upper half is rebuilt as the conjugate of the mirrored column (rows4_pack_mirror).
 template <int LOGL, bool HALF, int OUT = 0>
-__global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS, (HALF ? Rows4PackGeom<LOGL>::INV_WAVES_PER_SIMD : 1)) void fft_rows4_inv_packed_kernel(const RowArgs a0,
+__global__ __launch_bounds__((Rows4PackGeom<LOGL, true>::THREADS), (HALF ? Rows4PackGeom<LOGL, true>::INV_WAVES_PER_SIMD : 1)) void fft_rows4_inv_packed_kernel(const RowArgs a0,
                                                                                           const float2* __restrict__ tw_fwd) {
     RowArgs a = a0;
     if (a0.batch.nimg > 1) {  // blockIdx.y = image
@@ -818,10 +825,10 @@ __global__ __launch_bounds__(Rows4PackGeom<LOGL>::THREADS, (HALF ? Rows4PackGeom
         a.mm_part = pick_image(a0.batch.mm_part, blockIdx.y);
     }
     float fscale = 0.f, fshift = 0.f;
-    using Geo = Rows4PackGeom<LOGL>;
+    using Geo = Rows4PackGeom<LOGL, true>;
     using St = typename Geo::St;
     constexpr int G = Geo::G, T = St::T;
-    constexpr int NBUF = (HALF && LOGL >= FDR_ROWS_INV_NBUF1_MIN) ? 1 : 2;  // 1: one exchange buffer per thread group (more workgroups per CU)
+    constexpr int NBUF = (HALF && LOGL >= FDR_ROWS_INV_NBUF1_MIN && Geo::LOGV == 4) ? 1 : 2;  // 1: one exchange buffer per thread group (more workgroups per CU)
     using Core = FftCore<LOGL, 2, NBUF, PolicyFast, Geo::LOGV, (St::lr(0) == 1 && T >= 64 && FDR_SWAP0)>;
     __shared__ float2 lds[G * NBUF * St::BUF];
     const int g = threadIdx.x >> St::LOGT, tid = Core::thread_index(threadIdx.x & (T - 1));
@@ -943,9 +950,12 @@ __global__ __launch_bounds__((RowsPersGeom<LOGL, LOGV>::THREADS), (RowsPersGeom<
 #ifndef FDR_ROWS_SPLIT
 #define FDR_ROWS_SPLIT 1
 #endif
-template <int LOGL>
+// (INV: the inverse kernel follows the batched inverse kernels' step plan -- 16 values per thread from FDR_ROWS_INV_V16_MIN points
+// on -- so that ONE image restored alone and the same image inside a batch come out with identical bits.)
+template <int LOGL, bool INV = false>
 struct RowsSplitGeom {
-    using St = Steps<LOGL, 3>;
+    static constexpr int LOGV = Rows4PackGeom<LOGL, INV>::LOGV;
+    using St = Steps<LOGL, LOGV>;
     static constexpr int T = St::T;
     static constexpr int THREADS = 2 * T;
     static constexpr bool SWAP = St::lr(0) == 1 && T >= 64 && FDR_SWAP0;
@@ -1026,11 +1036,11 @@ __global__ __launch_bounds__(RowsSplitGeom<LOGL>::THREADS) void fft_rows4_fwd_sp
 
 // OUT as in rows4_inv_epilogue: 0 raw real plane + min/max, 1 min/max only, 2 normalised and cropped
 template <int LOGL, int OUT>
-__global__ __launch_bounds__(RowsSplitGeom<LOGL>::THREADS) void fft_rows4_inv_split_kernel(const RowArgs a, const float2* __restrict__ tw_fwd) {
-    using Geo = RowsSplitGeom<LOGL>;
+__global__ __launch_bounds__((RowsSplitGeom<LOGL, true>::THREADS)) void fft_rows4_inv_split_kernel(const RowArgs a, const float2* __restrict__ tw_fwd) {
+    using Geo = RowsSplitGeom<LOGL, true>;
     using St = typename Geo::St;
-    constexpr int T = St::T, L = St::L, V = 8;
-    using Core = FftCore<LOGL, 1, 2, PolicyFast, 3, Geo::SWAP>;
+    constexpr int T = St::T, L = St::L, V = St::V;
+    using Core = FftCore<LOGL, 1, 2, PolicyFast, Geo::LOGV, Geo::SWAP>;
     static_assert(Core::RHO0 >= 2 && Core::LOGR0 >= 2, "n = t + q Q with Q a multiple of 4");
     constexpr int HQ = Core::RHO0 / 2;
     __shared__ float2 lds[2 * 2 * St::BUF];
@@ -1170,19 +1180,21 @@ static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const f
     const int groups = (a.M + 3) / 4;
     const int nimg = a.batch.nimg > 1 ? a.batch.nimg : 1;
     const dim3 grid((groups + Geo::G - 1) / Geo::G, nimg), block(Geo::THREADS);
+    using IGeo = Rows4PackGeom<LOGL, true>;  // the inverse kernels' own thread-group shape
+    const dim3 igrid((groups + IGeo::G - 1) / IGeo::G, nimg), iblock(IGeo::THREADS);
     if constexpr (LOGL >= 8 && LOGL <= 11) {
         if (rows4_use_split(LOGL, a.M, nimg, a.half)) {  // one small image: two thread groups per 4-row group (see above)
             using SG = RowsSplitGeom<LOGL>;
-            const dim3 sgrid(a.M / 4), sblock(SG::THREADS);
+            const dim3 sgrid(a.M / 4), sblock(SG::THREADS), siblock(RowsSplitGeom<LOGL, true>::THREADS);
             if (in == ROW_IN_REAL && out == ROW_OUT_COMPLEX) {
                 if (a.src_rows <= 0 || a.src_cols <= 0) return hipErrorInvalidValue;
                 hipLaunchKernelGGL((fft_rows4_fwd_split_kernel<LOGL>), sgrid, sblock, 0, s, a, tw);
             } else if (in == ROW_IN_COMPLEX && out == ROW_OUT_REAL_MINMAX) {
-                hipLaunchKernelGGL((fft_rows4_inv_split_kernel<LOGL, 0>), sgrid, sblock, 0, s, a, tw);
+                hipLaunchKernelGGL((fft_rows4_inv_split_kernel<LOGL, 0>), sgrid, siblock, 0, s, a, tw);
             } else if (in == ROW_IN_COMPLEX && out == ROW_OUT_MINMAX_ONLY) {
-                hipLaunchKernelGGL((fft_rows4_inv_split_kernel<LOGL, 1>), sgrid, sblock, 0, s, a, tw);
+                hipLaunchKernelGGL((fft_rows4_inv_split_kernel<LOGL, 1>), sgrid, siblock, 0, s, a, tw);
             } else if (in == ROW_IN_COMPLEX && out == ROW_OUT_NORMALIZED) {
-                hipLaunchKernelGGL((fft_rows4_inv_split_kernel<LOGL, 2>), sgrid, sblock, 0, s, a, tw);
+                hipLaunchKernelGGL((fft_rows4_inv_split_kernel<LOGL, 2>), sgrid, siblock, 0, s, a, tw);
             } else {
                 return hipErrorInvalidValue;
             }
@@ -1215,13 +1227,13 @@ static hipError_t launch_rows4_t(RowIn in, RowOut out, const RowArgs& a, const f
         if (a.half) hipLaunchKernelGGL((fft_rows4_fwd_packed_kernel<LOGL, true>), grid, block, 0, s, a, tw);
         else hipLaunchKernelGGL((fft_rows4_fwd_packed_kernel<LOGL, false>), grid, block, 0, s, a, tw);
     } else if (in == ROW_IN_COMPLEX && out == ROW_OUT_REAL_MINMAX) {
-        return launch_rows4_inv_t<LOGL, 0>(a, tw, s, groups, nimg, grid, block);
+        return launch_rows4_inv_t<LOGL, 0>(a, tw, s, groups, nimg, igrid, iblock);
     } else if (in == ROW_IN_COMPLEX && out == ROW_OUT_MINMAX_ONLY) {
         if (!a.half) return hipErrorInvalidValue;  // two-sweep normalisation: half-spectrum path only
-        return launch_rows4_inv_t<LOGL, 1>(a, tw, s, groups, nimg, grid, block);
+        return launch_rows4_inv_t<LOGL, 1>(a, tw, s, groups, nimg, igrid, iblock);
     } else if (in == ROW_IN_COMPLEX && out == ROW_OUT_NORMALIZED) {
         if (!a.half) return hipErrorInvalidValue;
-        return launch_rows4_inv_t<LOGL, 2>(a, tw, s, groups, nimg, grid, block);
+        return launch_rows4_inv_t<LOGL, 2>(a, tw, s, groups, nimg, igrid, iblock);
     } else {
         return hipErrorInvalidValue;
     }
@@ -1234,7 +1246,7 @@ static int rows4_partials_t(int M, int num_cu, int nimg, int half) {
     if constexpr (LOGL >= FDR_ROWS_INV_PERS_MIN_LOG && FDR_ROWS_PERSISTENT) {
         if (rows4_inv_use_pers<LOGL>(M, num_cu, nimg)) return rows4_inv_pers_grid<LOGL>(M, num_cu, nimg);
     }
-    return ((M + 3) / 4 + Rows4PackGeom<LOGL>::G - 1) / Rows4PackGeom<LOGL>::G;
+    return ((M + 3) / 4 + Rows4PackGeom<LOGL, true>::G - 1) / Rows4PackGeom<LOGL, true>::G;
 }
 
 #define FDR_DISPATCH_LOG(var, expr)                                                     \
