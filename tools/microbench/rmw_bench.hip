@@ -5,6 +5,8 @@
 //   (c) tile-out    : as (b) but the result goes to a second buffer (not in place)
 //   (d) copy        : 4 x 64 MiB -> other buffer, no filter                                              (reference point)
 //   (e) / (f) / (g) : read-only over all images / over one image; copy of one image (does the 256 MiB Infinity Cache show?)
+//   (h) / (i)       : the inverse row passes' gather as 8-byte loads / as 32-byte rows of a panel, at 7 / 4 / 2 workgroups per CU
+//   (j) / (k)       : pass A's input rows as one dword / one float4 per lane and load (6.7 vs 7.1 TB/s: not what bounds pass A)
 //   usage: rmw_bench [images=4] [MiB per image=64] [iterations=20]
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -30,6 +32,34 @@ __global__ void read_kernel(const float4* __restrict__ a, float* __restrict__ si
     float acc = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { const float4 v = a[i]; acc += v.x + v.y + v.z + v.w; }
     if (acc == 1.2345e-30f) sink[0] = acc;
+}
+// pass A's input shape: a workgroup reads 4 rows of 4096 floats, one DWORD per lane and load (64 loads per lane), and writes nothing
+__global__ __launch_bounds__(256, 2) void rows_dword_kernel(const float* __restrict__ a, float* __restrict__ sink, int rows_total) {
+    const size_t r0 = (size_t)blockIdx.x * 4;
+    float acc = 0.f;
+    float v[4][16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[r][q] = __builtin_nontemporal_load(a + (r0 + r) * 4096 + threadIdx.x + 256 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc += v[r][q];
+    if (acc == 1.2345e-30f) sink[0] = acc;
+    (void)rows_total;
+}
+// the same bytes as one float4 per lane and load (16 loads per lane): lane t takes columns 4 (t & 63) + 256 q' .. of row t >> 6
+__global__ __launch_bounds__(256, 2) void rows_f4_kernel(const float4* __restrict__ a, float* __restrict__ sink, int rows_total) {
+    const size_t r0 = (size_t)blockIdx.x * 4;
+    float acc = 0.f;
+    float4 v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = a[(r0 + (threadIdx.x >> 6)) * 1024 + (threadIdx.x & 63) + 64 * q];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc += v[q].x + v[q].y + v[q].z + v[q].w;
+    if (acc == 1.2345e-30f) sink[0] = acc;
+    (void)rows_total;
 }
 __global__ void copy_kernel(const float4* __restrict__ a, float4* __restrict__ b, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -129,6 +159,11 @@ int main(int argc, char** argv) {
     timeit("(g) copy, ONE image", (double)n_img * 16 * 2, [&] { hipLaunchKernelGGL(copy_kernel, dim3(8192), dim3(256), 0, 0, a, b, n_img); });
     if (mib == 64 && (size_t)512 * kPS * 8 <= n_img * 16 + (size_t)images * 0) {
         // (an image of 512 panels x kPS float2 = 64.06 MiB: the images overlap by 64 KiB in this buffer, which only reads care about)
+    }
+    if (mib == 64) {
+        const int rows = 4096 * images;
+        timeit("(j) pass A's input: 4 rows per workgroup, one dword per lane and load", (double)rows * 4096 * 4, [&] { hipLaunchKernelGGL(rows_dword_kernel, dim3(rows / 4), dim3(256), 0, 0, (const float*)a, (float*)b, rows); });
+        timeit("(k) the same rows, one float4 per lane and load", (double)rows * 4096 * 4, [&] { hipLaunchKernelGGL(rows_f4_kernel, dim3(rows / 4), dim3(256), 0, 0, (const float4*)a, (float*)b, rows); });
     }
     {
         const size_t img_elems = (size_t)512 * kPS;  // float2 elements per image
