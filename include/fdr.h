@@ -80,7 +80,9 @@ int fdr_optimal_dft_size(int n);
 
 /* -- plan: owns twiddle tables, the M x N complex workspace, the filter spectrum and the
  *    min/max scratch for one device.  Replaces the per-call cudaMalloc/cudaFree block of
- *    fft/fft_gpu.cu:304-322,389-393.  One host thread at a time per plan.               */
+ *    fft/fft_gpu.cu:304-322,389-393.  One host thread at a time per plan.  fdr_plan_destroy
+ *    called while the process is already running its exit handlers (static destructors of a
+ *    caller) frees the host side only: the HIP runtime may be gone by then.              */
 int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan** out);
 int fdr_plan_destroy(fdr_plan* plan);
 int fdr_plan_dims(const fdr_plan* plan, int* M, int* N, int* mode);
@@ -265,7 +267,10 @@ typedef struct fdr_batch_desc {
                             loaded: the MPI_Bcast / MPI_Scatterv of the padded PSF in the reference's MPI variant
                             (fft/fft_mpi.cpp:334-378).  Needs count >= n_devices.  fdr_batch_stats::filter_path says which.
                             2: the same, and the RCCL path is taken even for a single device entry (a broadcast to itself:
-                            exercises the library and the call on a one-GPU machine). */
+                            exercises the library and the call on a one-GPU machine).
+                            UNEXERCISED ON HARDWARE for more than one distinct device (no multi-GPU machine has been
+                            available to the builds so far): any RCCL error there falls back to the peer copies (a line
+                            on stderr says so, filter_path reports FDR_FILTER_PEER_COPY) instead of failing the batch. */
 } fdr_batch_desc;
 
 #define FDR_BATCH_MAX_DEVICES 16
@@ -276,7 +281,8 @@ typedef struct fdr_batch_stats {
     double elapsed_ms[FDR_BATCH_MAX_DEVICES]; /* worker g: wall time of its timed region */
     double checksum[FDR_BATCH_MAX_DEVICES];   /* sum of worker g's restored pixels (last pass) */
     int status[FDR_BATCH_MAX_DEVICES];     /* FDR_OK or the failing status of worker g */
-    double wall_ms;                        /* all workers: from the common start to the last one's finish */
+    double wall_ms;                        /* all workers: from the common start line (every worker has finished its set-up
+                                              and warm-up and waits for the others there) to the last one's finish */
     long long images_done;                 /* sum over workers of images x passes */
     double mpixels_per_s;                  /* images_done * rows * cols / wall_ms */
     int filter_path;                       /* FDR_FILTER_*: how the workers came by their filter */

@@ -65,11 +65,26 @@ struct Profiler {
 // times the entry point (gpu.cpp:96-105), loops over the channels (serial.cpp:34-39) or calls once per picture of one size
 // pays for the twiddle tables, the workspaces and their hipFree once per thread (measured on 782 x 1920: the timed
 // _optimized call 17.6 -> 1.1 ms).  wienerDeblur_RGB_naive keeps allocating per channel, as its name says.  Per thread (a plan serves
-// one host thread at a time), at most four plans, oldest evicted; never destroyed at exit (the process is going away, and
-// the HIP runtime may already have).
+// one host thread at a time), at most plan_cache_capacity() plans (default 4), least recently used evicted.  The reference
+// frees everything per call (fft/fft_gpu.cu:389-393); what this header retains instead is bounded and released:
+//   * when the owning thread ends (the cache is a thread_local OBJECT; its destructor destroys every plan -- on the main
+//     thread that happens at exit() before any atexit handler, i.e. while the HIP runtime is still up; once the process is
+//     past that point fdr_plan_destroy only frees host memory, see fdr.h),
+//   * on demand: fft_gpu::release_cached_plans() (this thread's), fft_gpu::set_plan_cache_capacity(n) (0 = keep nothing
+//     between calls: the reference's behaviour).
 struct PlanCache {
     struct Entry { int device, M, N, mode; unsigned flags; fdr_plan* plan; };
     std::vector<Entry> entries;
+    PlanCache() = default;
+    PlanCache(const PlanCache&) = delete;
+    PlanCache& operator=(const PlanCache&) = delete;
+    ~PlanCache() { clear(); }
+    void clear() {
+        for (Entry& e : entries) fdr_plan_destroy(e.plan);
+        entries.clear();
+    }
+    static std::atomic<int>& capacity() { static std::atomic<int> c{4}; return c; }
+    // A plan handed out with capacity 0 is not retained: the caller destroys it (see PlanLease).
     fdr_plan* get(int device, int M, int N, int mode, bool* created, unsigned flags = 0u) {
         for (size_t i = 0; i < entries.size(); ++i)
             if (entries[i].device == device && entries[i].M == M && entries[i].N == N && entries[i].mode == mode && entries[i].flags == flags) {
@@ -79,15 +94,24 @@ struct PlanCache {
                 *created = false;
                 return e.plan;
             }
-        if (entries.size() >= 4) { fdr_plan_destroy(entries.front().plan); entries.erase(entries.begin()); }
+        const int cap = capacity().load();
+        while (!entries.empty() && (int)entries.size() >= (cap > 0 ? cap : 1)) { fdr_plan_destroy(entries.front().plan); entries.erase(entries.begin()); }
         fdr_plan* plan = nullptr;
         FDR_CHECK(fdr_plan_create(device, M, N, mode, flags, &plan));
         entries.push_back(Entry{device, M, N, mode, flags, plan});
         *created = true;
         return plan;
     }
+    // end of an entry point: with capacity 0 nothing stays allocated between calls
+    void settle() { if (capacity().load() <= 0) clear(); }
 };
-inline PlanCache& plan_cache() { static thread_local PlanCache* c = new PlanCache(); return *c; }
+inline PlanCache& plan_cache() { static thread_local PlanCache c; return c; }
+// Destroys the calling thread's cached plans now (device workspaces, filter, staging buffers, streams).
+inline void release_cached_plans() { plan_cache().clear(); }
+// Plans kept per thread between calls (default 4); 0 = allocate and free inside every call, as fft/fft_gpu.cu:304-322,389-393.
+inline void set_plan_cache_capacity(int n) { PlanCache::capacity().store(n < 0 ? 0 : n); if (n <= 0) plan_cache().clear(); }
+inline int plan_cache_capacity() { return PlanCache::capacity().load(); }
+struct PlanCacheSettle { ~PlanCacheSettle() { plan_cache().settle(); } };
 
 inline Mat run_channel(fdr_plan* plan, const Mat& img, int norm_area) {
     Mat src = img.isContinuous() ? img : img.clone();
@@ -102,6 +126,7 @@ inline void wienerDeblur_RGB_optimized(std::vector<Mat>& channels, const Mat& ps
     Profiler p;
     const int imgRows = channels[0].rows, imgCols = channels[0].cols;
     bool created = false;
+    PlanCacheSettle settle_;
     fdr_plan* plan = plan_cache().get(o.device, nextPowerOfTwo(imgRows), nextPowerOfTwo(imgCols), o.mode, &created);
     if (!created) { float discard[FDR_N_PHASES]; FDR_CHECK(fdr_plan_phase_times(plan, discard, 1)); }  // this call's phases only ([1. Allocation] = 0: reused)
     Mat psfc = psf.isContinuous() ? psf : psf.clone();
@@ -159,6 +184,7 @@ inline Mat wienerDeblur_myfft(const Mat& img, const Mat& psf, float K, const Opt
     const int M = fdr_optimal_dft_size(img.rows), N = fdr_optimal_dft_size(img.cols);
     const unsigned flags = (isPowerOfTwo(M) && isPowerOfTwo(N)) ? 0u : FDR_FLAG_ANY_SIZE;
     bool created = false;
+    PlanCacheSettle settle_;
     fdr_plan* plan = plan_cache().get(o.device, M, N, o.mode, &created, flags);
     Mat psfc = psf.isContinuous() ? psf : psf.clone();
     FDR_CHECK(fdr_set_psf(plan, psfc.ptr<float>(0), psf.rows, psf.cols, psf.cols, K));
@@ -231,6 +257,7 @@ inline Mat wienerDeblur_myfft(const Mat& img, const Mat& psf, float K) {
     const int M = fdr_optimal_dft_size(img.rows), N = fdr_optimal_dft_size(img.cols);
     const unsigned flags = (isPowerOfTwo(M) && isPowerOfTwo(N)) ? 0u : FDR_FLAG_ANY_SIZE;
     bool created = false;
+    fft_gpu::PlanCacheSettle settle_;
     fdr_plan* plan = fft_gpu::plan_cache().get(0, M, N, FDR_MODE_PARITY, &created, flags);  // kept between the channels of a driver's loop
     float ph[FDR_N_PHASES] = {0}, ms[FDR_MAX_PASSES] = {0};
     if (!created) FDR_CHECK(fdr_plan_phase_times(plan, ph, 1));  // this call's phases only

@@ -8,6 +8,8 @@ consistency check and, optionally (bench.py --bcast-filter), (iv) a broadcast of
 filter W in place of every rank recomputing it (setup, outside the timed region).  Partitioning follows the reference's calculate_distribution
 (fft/fft_mpi.cpp:89-100) applied to images instead of rows.
 """
+import os
+import sys
 import time
 
 
@@ -22,53 +24,82 @@ def calculate_distribution(total, parts):
 
 
 class Comm:
-    """Minimal wrapper so the same code runs single-process, under gloo (CPU tests) and under RCCL."""
+    """Minimal wrapper so the same code runs single-process, under gloo (CPU tests) and under RCCL.
 
-    def __init__(self, backend=None, device=None):
-        import os
+    Under "nccl" the process group is bound to this rank's device at creation (`device_id`: the communicator is built
+    eagerly on that device, so a barrier can never pick another one) and every collective has a deadline
+    (FDR_DIST_TIMEOUT_S, default 300 s).  A collective that raises ends the process with a one-line message and a
+    non-zero exit code -- the launcher then stops the other ranks -- instead of leaving them waiting."""
+
+    def __init__(self, backend=None, device=None, timeout_s=None):
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.dist = None
         self.device = device
+        self.backend = backend or "nccl"
         if self.world > 1:
+            import datetime
             import torch.distributed as dist
             if not dist.is_initialized():
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", "29511")
-                dist.init_process_group(backend=backend or "nccl", rank=self.rank, world_size=self.world)
+                if timeout_s is None:
+                    timeout_s = float(os.environ.get("FDR_DIST_TIMEOUT_S", "300"))
+                kw = {"timeout": datetime.timedelta(seconds=timeout_s)}
+                if self.backend == "nccl" and device is not None:
+                    kw["device_id"] = device
+                self._guard("init_process_group", lambda: dist.init_process_group(
+                    backend=self.backend, rank=self.rank, world_size=self.world, **kw))
+            else:
+                self.backend = dist.get_backend()
             self.dist = dist
+
+    def _guard(self, what, fn):
+        try:
+            return fn()
+        except BaseException as e:  # noqa: BLE001 -- any failure of a collective ends this rank, loudly
+            if isinstance(e, (KeyboardInterrupt, SystemExit)):
+                raise
+            sys.stderr.write("fdr.batch: rank %d/%d: %s failed (backend %s): %s: %s\n"
+                             % (self.rank, self.world, what, self.backend, type(e).__name__, e))
+            sys.stderr.flush()
+            os._exit(13)  # no destructors: tearing a broken process group down can itself wait for the peers
 
     def _tensor(self, vals, dtype):
         import torch
-        dev = self.device if (self.dist is not None and self.dist.get_backend() == "nccl") else "cpu"
+        dev = self.device if (self.dist is not None and self.backend == "nccl") else "cpu"
         return torch.tensor(vals, dtype=dtype, device=dev)
 
     def barrier(self):
-        if self.dist is not None:
-            self.dist.barrier()
+        if self.dist is None:
+            return
+        if self.backend == "nccl" and self.device is not None and getattr(self.device, "index", None) is not None:
+            self._guard("barrier", lambda: self.dist.barrier(device_ids=[self.device.index]))
+        else:
+            self._guard("barrier", self.dist.barrier)
+
+    def _allreduce(self, vals, op, what):
+        import torch
+        t = self._tensor([float(v) for v in vals], torch.float64)
+        self._guard(what, lambda: self.dist.all_reduce(t, op=op))
+        return [float(v) for v in t.tolist()]
 
     def allreduce_max(self, x):
         if self.dist is None:
             return float(x)
-        import torch
-        t = self._tensor([float(x)], torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
+        return self._allreduce([x], self.dist.ReduceOp.MAX, "all_reduce(MAX)")[0]
 
     def allreduce_min(self, x):
         if self.dist is None:
             return float(x)
-        import torch
-        t = self._tensor([float(x)], torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
-        return float(t.item())
+        return self._allreduce([x], self.dist.ReduceOp.MIN, "all_reduce(MIN)")[0]
 
     def broadcast(self, tensor, src=0):
         """dist.broadcast of a tensor in place (RCCL over xGMI under "nccl"); the data-carrying collective of the batched mode
         (rank 0's prepared filter W to every rank: the MPI_Bcast / Scatterv of fft/fft_mpi.cpp:334-378).  Single process: no-op."""
         if self.dist is not None:
-            self.dist.broadcast(tensor, src=src)
+            self._guard("broadcast", lambda: self.dist.broadcast(tensor, src=src))
         return tensor
 
     def gather_objects(self, obj):
@@ -76,20 +107,17 @@ class Comm:
         if self.dist is None:
             return [obj]
         out = [None] * self.world if self.rank == 0 else None
-        self.dist.gather_object(obj, out, dst=0)
+        self._guard("gather_object", lambda: self.dist.gather_object(obj, out, dst=0))
         return out
 
     def allreduce_sum(self, vals):
         if self.dist is None:
             return [float(v) for v in vals]
-        import torch
-        t = self._tensor([float(v) for v in vals], torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return [float(v) for v in t.tolist()]
+        return self._allreduce(vals, self.dist.ReduceOp.SUM, "all_reduce(SUM)")
 
     def close(self):
         if self.dist is not None and self.dist.is_initialized():
-            self.dist.destroy_process_group()
+            self._guard("destroy_process_group", self.dist.destroy_process_group)
 
 
 def timed_steps(comm, step_fn, sync_fn, steps, warmup):

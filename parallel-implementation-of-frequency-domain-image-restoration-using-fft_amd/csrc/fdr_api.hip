@@ -11,6 +11,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -20,6 +23,7 @@ using namespace fdr;
 namespace {
 
 thread_local std::string g_last_error;
+std::atomic<bool> g_process_exiting{false};  // set by an atexit handler that runs before the HIP runtime's own (fdr_plan_destroy)
 
 int fail(int code, const std::string& msg) {
     g_last_error = msg;
@@ -185,6 +189,7 @@ struct fdr_plan {
         float* d_out[3] = {nullptr, nullptr, nullptr};
         hipEvent_t e_in[3] = {nullptr, nullptr, nullptr}, e_cmp[3] = {nullptr, nullptr, nullptr}, e_out[3] = {nullptr, nullptr, nullptr};
         size_t cap = 0;  // bytes of each d_in / d_out buffer
+        bool ready = false;  // all three streams and nine events exist
     } pipe;
     bool batch_graph = false;
     hipGraphExec_t graph_exec = nullptr;
@@ -699,6 +704,9 @@ int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan
     }
     if (M > 8192 || N > 8192) return fail(FDR_ERR_ARG, "fdr_plan_create: dimension above 8192 (one row must fit LDS)");
     FDR_HIP(hipSetDevice(device));
+    // registered behind the first HIP call, i.e. after the HIP runtime's own exit handlers: it runs BEFORE them
+    static std::once_flag exit_hook;
+    std::call_once(exit_hook, [] { std::atexit([] { g_process_exiting.store(true); }); });
     const auto t0 = std::chrono::steady_clock::now();
     fdr_plan* p = new (std::nothrow) fdr_plan();
     if (!p) return fail(FDR_ERR_ALLOC, "fdr_plan_create: out of host memory");
@@ -716,6 +724,10 @@ int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan
 
 int fdr_plan_destroy(fdr_plan* p) {
     if (!p) return FDR_OK;
+    if (g_process_exiting.load()) {  // static destructors / late atexit handlers: the HIP runtime may be gone; the
+        delete p;                    // process's device memory goes with it, only the host side is ours to free
+        return FDR_OK;
+    }
     (void)hipSetDevice(p->device);
     for (int k = 1; k < fdr_plan::kMaxSlots; ++k) {
         fdr_plan::Slot& w = p->slots[k];
@@ -1130,15 +1142,20 @@ int fdr_wiener_batch_ptrs_f32(fdr_plan* p, const float* const* imgs_host, float*
     const size_t bytes = (size_t)rows * cols * sizeof(float), rowb = (size_t)cols * sizeof(float);
     // streams, events and device staging live in the plan (created on first use, sized for the plan's M x N)
     fdr_plan::HostPipe& hp = p->pipe;
-    if (!hp.s_in) {
-        FDR_HIP(hipStreamCreateWithFlags(&hp.s_in, hipStreamNonBlocking));
-        FDR_HIP(hipStreamCreateWithFlags(&hp.s_cmp, hipStreamNonBlocking));
-        FDR_HIP(hipStreamCreateWithFlags(&hp.s_out, hipStreamNonBlocking));
-        for (int k = 0; k < D; ++k) {
-            FDR_HIP(hipEventCreateWithFlags(&hp.e_in[k], hipEventDisableTiming));
-            FDR_HIP(hipEventCreateWithFlags(&hp.e_cmp[k], hipEventDisableTiming));
-            FDR_HIP(hipEventCreateWithFlags(&hp.e_out[k], hipEventDisableTiming));
+    if (!hp.ready) {  // built into locals and committed only when every stream and event exists (failure-atomic)
+        hipStream_t st[3] = {nullptr, nullptr, nullptr};
+        hipEvent_t ev[3 * D] = {};
+        hipError_t ce = hipSuccess;
+        for (int k = 0; k < 3 && ce == hipSuccess; ++k) ce = hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking);
+        for (int k = 0; k < 3 * D && ce == hipSuccess; ++k) ce = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+        if (ce != hipSuccess) {
+            for (int k = 0; k < 3; ++k) if (st[k]) (void)hipStreamDestroy(st[k]);
+            for (int k = 0; k < 3 * D; ++k) if (ev[k]) (void)hipEventDestroy(ev[k]);
+            FDR_HIP(ce);
         }
+        hp.s_in = st[0]; hp.s_cmp = st[1]; hp.s_out = st[2];
+        for (int k = 0; k < D; ++k) { hp.e_in[k] = ev[3 * k]; hp.e_cmp[k] = ev[3 * k + 1]; hp.e_out[k] = ev[3 * k + 2]; }
+        hp.ready = true;
     }
     if (hp.cap < bytes) {
         const size_t cap = (size_t)p->M * p->N * sizeof(float);
@@ -1434,8 +1451,25 @@ __global__ void checksum_kernel(const float* __restrict__ x, size_t count, doubl
 
 // `prepared`: a plan that already holds its filter (fdr_batch_desc::bcast_filter: created and filled by the calling thread,
 // which has synchronised the device); the worker owns it from here on.  nullptr: the worker builds plan and filter itself.
-int batch_worker_run(const fdr_batch_desc* d, BatchWorker* w, std::chrono::steady_clock::time_point* t_start_out, fdr_plan* prepared) {
+// Start line of fdr_batch_run's workers: set-up (plan, PSF spectrum, synthesis, warm-up) differs from device to device, so
+// every worker waits here until all of them are ready and the timed regions start together; `wall_ms` then spans the work
+// itself, not the set-up skew.  A worker that fails before the line still arrives (without waiting), so nobody waits for it.
+struct StartGate {
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0, total = 0;
+    explicit StartGate(int n) : total(n) {}
+    void arrive(bool wait) {
+        std::unique_lock<std::mutex> lk(m);
+        if (++arrived >= total) { cv.notify_all(); return; }
+        if (wait) cv.wait(lk, [&] { return arrived >= total; });
+    }
+};
+
+int batch_worker_run(const fdr_batch_desc* d, BatchWorker* w, std::chrono::steady_clock::time_point* t_start_out, fdr_plan* prepared, StartGate* gate) {
     fdr_plan* plan = prepared;
+    bool at_gate = false;
+    auto start_line = [&] { at_gate = true; gate->arrive(true); };
     float *d_in = nullptr, *d_out = nullptr;
     double* d_part = nullptr;
     hipStream_t stream = nullptr;
@@ -1457,6 +1491,8 @@ int batch_worker_run(const fdr_batch_desc* d, BatchWorker* w, std::chrono::stead
         }
         if (r != FDR_OK) return r;
         if (d->imgs_host) {  // host images: the pipelined host batch over this worker's shard
+            FDR_HIP(hipStreamSynchronize(stream));  // (the PSF spectrum is part of the set-up)
+            start_line();
             const auto t0 = std::chrono::steady_clock::now();
             *t_start_out = t0;
             r = fdr_wiener_batch_ptrs_f32(plan, d->imgs_host + w->first, d->outs_host + w->first, w->count, d->rows, d->cols, d->stride,
@@ -1489,6 +1525,7 @@ int batch_worker_run(const fdr_batch_desc* d, BatchWorker* w, std::chrono::stead
             r = fdr_wiener_batch_f32_dev(plan, d_in, P, w->count, d->rows, d->cols, d->cols, d_out, P, d->cols, d->norm_area, stream);
         FDR_HIP(hipStreamSynchronize(stream));
         if (r != FDR_OK) return r;
+        start_line();
         const auto t0 = std::chrono::steady_clock::now();
         *t_start_out = t0;
         for (int k = 0; k < d->steps && r == FDR_OK; ++k)
@@ -1509,6 +1546,7 @@ int batch_worker_run(const fdr_batch_desc* d, BatchWorker* w, std::chrono::stead
     };
     if (hipSetDevice(w->device) != hipSuccess) rc = fail(FDR_ERR_HIP, "fdr_batch_run: hipSetDevice failed");
     else rc = body();
+    if (!at_gate) gate->arrive(false);  // no images, or failed during set-up: count as arrived, do not hold the others up
     if (rc != FDR_OK) w->error = g_last_error;  // thread-local: hand it to the calling thread
     (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_part);
     if (stream) (void)hipStreamDestroy(stream);
@@ -1573,13 +1611,16 @@ int distribute_filter(const std::vector<fdr_plan*>& plans, float K, bool force_r
             const int ne = rccl.GroupEnd();
             if (nr == 0) nr = ne;
             for (int g = 0; g < G; ++g)
-                if (hipSetDevice(devs[g]) == hipSuccess) (void)hipDeviceSynchronize();
+                if (hipSetDevice(devs[g]) == hipSuccess && hipDeviceSynchronize() != hipSuccess && nr == 0) nr = -1;
             for (int g = 0; g < G; ++g)
                 if (comms[g]) (void)rccl.CommDestroy(comms[g]);
         }
-        if (nr != 0) return fail(FDR_ERR_HIP, std::string("fdr_batch_run: RCCL broadcast of the filter failed: ") + (rccl.GetErrorString && nr > 0 ? rccl.GetErrorString(nr) : "error"));
-        path = FDR_FILTER_RCCL_BROADCAST;
-    } else {
+        if (nr == 0) path = FDR_FILTER_RCCL_BROADCAST;
+        else  // the G > 1 RCCL path has not met multi-GPU hardware yet: an error there must not cost the batch
+            std::fprintf(stderr, "fdr_batch_run: RCCL broadcast of the filter failed (%s); falling back to peer copies\n",
+                         rccl.GetErrorString && nr > 0 ? rccl.GetErrorString(nr) : "error");
+    }
+    if (path != FDR_FILTER_RCCL_BROADCAST) {
         for (int g = 1; g < G; ++g) {
             FDR_HIP(hipSetDevice(plans[g]->device));
             if (plans[g]->device == plans[0]->device) FDR_HIP(hipMemcpy(plans[g]->filt, plans[0]->filt, bytes, hipMemcpyDeviceToDevice));
@@ -1638,8 +1679,9 @@ extern "C" int fdr_batch_run(const fdr_batch_desc* d, fdr_batch_stats* st) {
     const auto t_launch = std::chrono::steady_clock::now();
     for (int g = 0; g < G; ++g) { starts[g] = t_launch; ws[g].t_end = t_launch; }
     std::vector<std::thread> threads;
-    for (int g = 1; g < G; ++g) threads.emplace_back(batch_worker_run, d, &ws[g], &starts[g], prepared[g]);
-    batch_worker_run(d, &ws[0], &starts[0], prepared[0]);  // worker 0 on the calling thread
+    StartGate gate(G);
+    for (int g = 1; g < G; ++g) threads.emplace_back(batch_worker_run, d, &ws[g], &starts[g], prepared[g], &gate);
+    batch_worker_run(d, &ws[0], &starts[0], prepared[0], &gate);  // worker 0 on the calling thread
     for (auto& t : threads) t.join();
     int rc = FDR_OK;
     std::string msg;

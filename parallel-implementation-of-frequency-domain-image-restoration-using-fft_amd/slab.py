@@ -37,11 +37,13 @@ def alltoall_blocks(comm, send, send_counts, recv_counts):
         return send.clone()
     if comm.dist.get_backend() == "nccl":
         recv = torch.empty(int(sum(recv_counts)), dtype=send.dtype, device=send.device)
-        comm.dist.all_to_all_single(recv, send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts))
+        comm._guard("all_to_all_single", lambda: comm.dist.all_to_all_single(
+            recv, send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts)))
         return recv
     h_send = send.detach().cpu().contiguous()
     h_recv = torch.empty(int(sum(recv_counts)), dtype=send.dtype)
-    comm.dist.all_to_all_single(h_recv, h_send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts))
+    comm._guard("all_to_all_single", lambda: comm.dist.all_to_all_single(
+        h_recv, h_send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts)))
     return h_recv.to(send.device)
 
 
