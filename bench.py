@@ -379,23 +379,20 @@ def main():
             tfile = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tfile):
                 try:
-                    tj = json.load(open(tfile))
-                    key = "%s/%s/%d" % (args.mode, spectrum, S)
-                    if key in tj and base_name in tj[key]:
-                        ent = tj[key][base_name]  # PMC bytes per launch of `images` images (tools/summarize_profiles.py)
-                        if isinstance(ent, dict) and ent["images"] == nimg:
-                            roofline["traffic"] = ent["per_launch"]
-                        elif isinstance(ent, dict):
-                            # a launch of another size was profiled: scale the per-image part, keep W once (pass B')
-                            w_once = (4 if spectrum == "half" else 8) * P if base_name.startswith("B' cols") else 0
-                            roofline["traffic"] = (ent["per_launch"] - w_once) * nimg / ent["images"] + w_once
-                            roofline["traffic_note"] = "scaled from a %d-image launch" % ent["images"]
-                        else:
-                            roofline["traffic"] = ent * nimg
+                    # PMC bytes per launch come from a committed collection: they are reported only when that collection
+                    # was made on the kernel sources this run was built from (csrc fingerprint) -- else traffic_stale
+                    te = fdr.traffic_entry(json.load(open(tfile)), "%s/%s/%d" % (args.mode, spectrum, S), base_name, nimg,
+                                           fdr.csrc_fingerprint(), P, spectrum)
+                    roofline["traffic_stale"] = te["stale"]
+                    if te["note"]:
+                        roofline["traffic_note"] = te["note"]
+                    if te["traffic"] is not None:
+                        roofline["traffic"] = te["traffic"]
+                        roofline["traffic_kernel"] = te["kernel"]
                         roofline["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x 2 on gfx950)"
                         roofline["frac_by_counters"] = round(roofline["traffic"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
-                except Exception:
-                    pass
+                except Exception as e:  # noqa: BLE001 -- a malformed evidence file must not cost the bench line
+                    roofline["traffic_note"] = "profiles/traffic.json unreadable: %s" % e
         vals = sorted(images * P / 1e6 / t for t in reps)
         config = {"workload": "%dx%d synthetic fp32, PSF len=50 angle=30, K=0.01, single channel, device-resident" % (S, S),
                   "images_per_step": int(tot[3]), "images_per_gpu_per_step": B if scaling == "weak" else None,

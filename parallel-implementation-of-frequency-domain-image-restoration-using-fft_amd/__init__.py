@@ -176,6 +176,45 @@ def _stream(stream):
 
 
 # ---- utils.hpp mirrors ---------------------------------------------------------------------
+def csrc_fingerprint():
+    """sha256 (first 16 hex digits) over names and contents of csrc/*: which kernel sources a build, a profile or a bench
+    line belongs to.  tools/collect_profiles.sh records it beside the PMC passes, tools/summarize_profiles.py writes it into
+    profiles/traffic.json, and bench.py reports `roofline.traffic_stale` when the tree it runs from has another one."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp", ".h")):
+            h.update(name.encode() + b"\0")
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def traffic_entry(tj, key, pass_name, images, fingerprint, P, spectrum):
+    """Looks a pass up in profiles/traffic.json (PMC bytes per launch, tools/summarize_profiles.py) for bench.py's roofline.
+    Returns a dict: `traffic` (bytes per launch of `images` images, or None), `stale` (the counters were collected on other
+    kernel sources than `fingerprint`, or the entry carries no fingerprint: the bytes are then NOT reported), `note`."""
+    out = {"traffic": None, "stale": False, "note": None, "kernel": None}
+    ent = tj.get(key, {}).get(pass_name)
+    if ent is None:
+        out["note"] = "no PMC entry for %s / %s" % (key, pass_name)
+        return out
+    if not isinstance(ent, dict):
+        ent = {"per_launch": float(ent), "images": 1}
+    out["kernel"] = ent.get("kernel")
+    if ent.get("csrc") != fingerprint:
+        out["stale"] = True
+        out["note"] = "counters collected on csrc %s, this tree is %s" % (ent.get("csrc"), fingerprint)
+        return out
+    if ent["images"] == images:
+        out["traffic"] = ent["per_launch"]
+    else:  # a launch of another size was profiled: scale the per-image part, keep W once (pass B')
+        w_once = (4 if spectrum == "half" else 8) * P if pass_name.startswith("B' cols") else 0
+        out["traffic"] = (ent["per_launch"] - w_once) * images / ent["images"] + w_once
+        out["note"] = "scaled from a %d-image launch" % ent["images"]
+    return out
+
+
 def nextPowerOfTwo(n):
     """utils.hpp:27-31"""
     return lib.fdr_next_pow2(int(n))

@@ -189,3 +189,50 @@ def test_two_rank_gloo_alltoall_transpose_logic():
         assert out.returncode == 0, out.stderr[-2000:]
         r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
         assert r["world"] == world and r["ok"] is True, r
+
+
+def test_traffic_json_is_tied_to_the_kernel_sources(fdr, tmp_path):
+    """profiles/traffic.json entries carry the fingerprint of the csrc/ tree the counters were collected on; bench.py's
+    roofline (fdr.traffic_entry) reports the PMC bytes only for a matching tree and flags `traffic_stale` otherwise."""
+    fp = fdr.csrc_fingerprint()
+    assert re.fullmatch(r"[0-9a-f]{16}", fp)
+    P = 4096 * 4096
+    name = "B' cols: FFT*W*IFFT"
+    good = {"fast/half/4096": {name: {"per_launch": 36.0 * P, "images": 4, "kernel": "fdr::fft_cols_panel_fused16_kernel<12>",
+                                      "grid_threads": 524288, "workgroup_threads": 256, "csrc": fp, "collected": "rXX"}}}
+    te = fdr.traffic_entry(good, "fast/half/4096", name, 4, fp, P, "half")
+    assert te["stale"] is False and te["traffic"] == 36.0 * P and te["kernel"].endswith("fused16_kernel<12>")
+    # another launch size: the per-image part scales, W stays once
+    te = fdr.traffic_entry(good, "fast/half/4096", name, 2, fp, P, "half")
+    assert te["stale"] is False and te["traffic"] == 20.0 * P and "scaled" in te["note"]
+    # the same file, edited: counters from other sources -> flagged, no bytes reported
+    path = tmp_path / "traffic.json"
+    edited = json.loads(json.dumps(good))
+    edited["fast/half/4096"][name]["csrc"] = "0" * 16
+    path.write_text(json.dumps(edited))
+    te = fdr.traffic_entry(json.load(open(path)), "fast/half/4096", name, 4, fp, P, "half")
+    assert te["stale"] is True and te["traffic"] is None and "0000" in te["note"]
+    # an entry without a fingerprint (collections before round 4) is stale too; a missing entry is just absent
+    legacy = {"fast/half/4096": {name: {"per_launch": 36.0 * P, "images": 4}}}
+    assert fdr.traffic_entry(legacy, "fast/half/4096", name, 4, fp, P, "half")["stale"] is True
+    te = fdr.traffic_entry(good, "fast/half/8192", name, 2, fp, P, "half")
+    assert te["stale"] is False and te["traffic"] is None
+    # touching a kernel source changes the fingerprint (checked on a copy of the function's own recipe)
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, PKG, "csrc")
+    for n in sorted(os.listdir(d)):
+        if n.endswith((".hip", ".hpp", ".h")):
+            h.update(n.encode() + b"\0")
+            h.update(open(os.path.join(d, n), "rb").read() + (b" " if n == "fdr_panel.hip" else b""))
+    assert h.hexdigest()[:16] != fp
+
+
+def test_plan_cache_of_the_cpp_surface_is_bounded_and_released():
+    """include/fft/fft.hpp: the per-thread plan cache is an object with a destructor, has a capacity knob and a release
+    call (it used to be a leaked pointer).  Source-level check here; the GPU test runs the code."""
+    src = open(os.path.join(ROOT, "include", "fft", "fft.hpp")).read()
+    assert "static thread_local PlanCache c;" in src and "new PlanCache" not in src
+    assert "~PlanCache() { clear(); }" in src
+    for name in ("release_cached_plans", "set_plan_cache_capacity", "plan_cache_capacity"):
+        assert re.search(r"inline \w+ %s\(" % name, src), name

@@ -6,6 +6,7 @@
 #include "fft/fft.hpp"
 #include <cstdio>
 #include <string>
+#include <thread>
 
 static void dump(const std::string& path, const float* p, size_t n) {
     FILE* f = std::fopen(path.c_str(), "wb");
@@ -94,6 +95,35 @@ int main(int argc, char** argv) {
     Mat g2 = c2.clone();
     fft_gpu::my_dft2D(g2, true);
     dump(out + "fft2d_inv.f32", g2);
+    // the plan cache behind these entry points (include/fft/fft.hpp): bounded, released on demand and at thread exit, and
+    // with capacity 0 nothing is retained between calls (the reference's allocate-and-free behaviour, fft/fft_gpu.cu:389-393)
+    {
+        if (fft_gpu::plan_cache().entries.empty()) return 9;  // the calls above left plans behind
+        fft_gpu::release_cached_plans();
+        if (!fft_gpu::plan_cache().entries.empty()) return 10;
+        Mat r1 = fft_gpu::wienerDeblur_myfft(padded, psf, 0.01f);  // rebuilt from nothing: same pixels
+        fft_gpu::set_plan_cache_capacity(0);
+        if (!fft_gpu::plan_cache().entries.empty()) return 11;
+        Mat r2 = fft_gpu::wienerDeblur_myfft(padded, psf, 0.01f);
+        if (!fft_gpu::plan_cache().entries.empty()) return 12;  // nothing kept with capacity 0
+        for (int r = 0; r < r1.rows; ++r) for (int x = 0; x < r1.cols; ++x) if (r1.ptr<float>(r)[x] != r2.ptr<float>(r)[x]) return 13;
+        fft_gpu::set_plan_cache_capacity(2);
+        int rc_thread = 0;
+        std::thread th([&] {  // a thread that restores and ends: its cache object's destructor frees its plans
+            Mat r3 = fft_gpu::wienerDeblur_myfft(padded, psf, 0.01f);
+            for (int r = 0; r < r1.rows; ++r) for (int x = 0; x < r1.cols; ++x) if (r1.ptr<float>(r)[x] != r3.ptr<float>(r)[x]) rc_thread = 14;
+            if (fft_gpu::plan_cache().entries.size() != 1) rc_thread = 15;
+        });
+        th.join();
+        if (rc_thread) return rc_thread;
+        for (int k = 0; k < 4; ++k) {  // capacity 2: never more than two plans whatever sizes come by
+            Mat im(16 << k, 32, CV_32F);
+            for (int r = 0; r < im.rows; ++r) for (int c = 0; c < im.cols; ++c) im.ptr<float>(r)[c] = lcg(seed);
+            (void)fft_gpu::wienerDeblur_myfft(im, psf, 0.01f);
+            if (fft_gpu::plan_cache().entries.size() > 2) return 16;
+        }
+        fft_gpu::set_plan_cache_capacity(4);
+    }
     std::printf("shim ok\n");
     return 0;
 }

@@ -19,6 +19,8 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 make -s -C tools/microbench membench
+python3 -c "import importlib; print(importlib.import_module('parallel-implementation-of-frequency-domain-image-restoration-using-fft_amd').csrc_fingerprint())" > $OUT/csrc_fingerprint.txt
+export FDR_REQUIRE_REF_MAINS=1
 python3 bench.py > $OUT/bench_default.log 2>&1; echo "bench_default rc=$?" >> $OUT/status.txt
 grep '^{' $OUT/bench_default.log | tail -n 1 > $OUT/bench_line.json
 # the same with passes C' + E (raw real plane, 36 B/pixel) instead of the default two-sweep C1 + C2 (32 B/pixel)

@@ -45,11 +45,21 @@ def counter(path, name, grids=None):
     return collections.defaultdict(list, d)
 
 
-# threads one IMAGE's launch of a kernel has (one-group row kernels: M/4 groups x 256 threads; column tiles: N/8 tiles x T)
-def images_of(kname, grid, size, default):
+def workgroup_sizes(path):
+    """kernel name -> most frequent Workgroup_Size of its dispatches in a counter_collection.csv"""
+    raw = collections.defaultdict(collections.Counter)
+    for r in csv.DictReader(open(path)):
+        if r.get("Workgroup_Size"):
+            raw[r["Kernel_Name"]][int(r["Workgroup_Size"])] += 1
+    return {k: c.most_common(1)[0][0] for k, c in raw.items()}
+
+
+# threads one IMAGE's launch of a kernel has (one-group row kernels: M/4 groups x the workgroup size the trace reports --
+# 256 threads up to 4096 points, 512 for the 8192-point inverse kernel; column tiles: N/8 tiles x T)
+def images_of(kname, grid, size, default, wg=256):
     lg = size.bit_length() - 1
     if "fft_rows4_fwd_packed_kernel<%d" % lg in kname or "fft_rows4_inv_packed_kernel<%d" % lg in kname:
-        return max(1, round(grid / ((size // 4) * 256)))
+        return max(1, round(grid / ((size // 4) * (wg or 256))))
     if "fft_cols_panel_fused16_kernel<%d>" % lg in kname:
         return max(1, round(grid / ((size // 8) * (size // 16))))
     return default
@@ -69,6 +79,9 @@ def main():
     known_kib = 128 * 1024
     fetch_factor, write_factor = known_kib / cf, known_kib / cw
     print("calibration: FETCH_SIZE factor %.3f, WRITE_SIZE factor %.3f" % (fetch_factor, write_factor))
+    fp_path = os.path.join(src, "csrc_fingerprint.txt")  # written on the GPU box by collect_profiles.sh: the sources the counters saw
+    fingerprint = open(fp_path).read().strip() if os.path.exists(fp_path) else None
+    print("csrc fingerprint of the collection:", fingerprint)
     tj_path = os.path.join(dst, "traffic.json")
     tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
     for size in (4096, 8192):
@@ -99,6 +112,7 @@ def main():
             continue
         fgrids, wgrids = {}, {}
         fe, wr = counter(fe_f[0], "FETCH_SIZE", fgrids), counter(wr_f[0], "WRITE_SIZE", wgrids)
+        wgs = workgroup_sizes(fe_f[0])
         traffic, rows = {}, []
         default_images = 4 if size <= 4096 else 2  # images per launch of bench.py's default grouping (what the PMC runs used)
         for kname, vals in fe.items():
@@ -110,8 +124,10 @@ def main():
                     rd = statistics.median(vals) * round(fetch_factor) * 1024.0
                     wv = [v for k, v in wr.items() if k == kname]
                     wt = statistics.median(wv[0]) * 1024.0 if wv else 0.0
-                    images = images_of(kname, fgrids.get(kname, 0), size, default_images)
-                    traffic[pname] = {"per_launch": rd + wt, "images": images}
+                    images = images_of(kname, fgrids.get(kname, 0), size, default_images, wgs.get(kname))
+                    traffic[pname] = {"per_launch": rd + wt, "images": images, "kernel": kname.split("(")[0].replace("void ", ""),
+                                      "grid_threads": fgrids.get(kname, 0), "workgroup_threads": wgs.get(kname), "csrc": fingerprint,
+                                      "collected": tag}
                     rows.append((pname, kname[:90], len(vals), statistics.median(vals), statistics.median(wv[0]) if wv else 0, rd, wt, images))
         with open(os.path.join(dst, "%s_hbm_traffic_%d.csv" % (tag, size)), "w", newline="") as f:
             w = csv.writer(f)
