@@ -1635,6 +1635,23 @@ __global__ __launch_bounds__(PanelGeom<LOGM>::THREADS, PanelGeom<LOGM>::PIPE_WAV
 #define FDR_PARK_BASES 1  // 8192-point column pass: twiddle bases parked in LDS across the filter phase (A/B builds: 0)
 #endif
 
+// Phase stamps of pass B' (timing-only debug builds, -DFDR_DEBUG_STAMPS; read back by tools/microbench/passbench): the
+// shader-clock counter of wave 0 of every workgroup at start / tile landed / forward transform done / filter applied /
+// inverse transform done / stores issued / stores retired.  The waits the "landed" and "retired" stamps need are part of
+// such a build only.
+#ifdef FDR_DEBUG_STAMPS
+__device__ unsigned long long fdr_dbg_stamps[8192 * 8];
+#define FDR_STAMP(i) do { if (threadIdx.x == 0) fdr_dbg_stamps[((blockIdx.x + gridDim.x * blockIdx.y) & 8191) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define FDR_STAMP_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+extern "C" int fdr_debug_read_stamps(unsigned long long* out, size_t count) {
+    if (count > 8192 * 8) count = 8192 * 8;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fdr_dbg_stamps), count * sizeof(unsigned long long));
+}
+#else
+#define FDR_STAMP(i) ((void)0)
+#define FDR_STAMP_WAIT_VM() ((void)0)
+#endif
+
 template <int LOGM>
 struct Panel16Geom {
     static constexpr int T = Steps<LOGM, 4>::T;
@@ -1707,8 +1724,12 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
     // Without its filter (-DFDR_DEBUG_SKIP_W) the pass takes 28.6 us, and `tools/microbench/rmw_bench` moves the pass's
     // traffic alone -- four 64 MiB images in place plus one shared 64 MiB filter -- in 94-106 us, 24-26.5 us per image.)
     float2 v[4][V];
+    FDR_STAMP(0);
     tile_load<Core, false>(data, loff, 1u, v);
+    FDR_STAMP_WAIT_VM();
+    FDR_STAMP(1);
     Core::template run<0, false>(v, grp_lds, tw_fwd, bases, tid);
+    FDR_STAMP(2);
 
     const bool packed_tile = packed0 && tl == 0;  // uniform per workgroup
     constexpr int SEQ = Core::SLOTS;
@@ -1797,6 +1818,7 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
             wmul(h + 1, wb);
         }
     }
+    FDR_STAMP(3);
     {
         // opaque copy of the thread index: the inverse transform's LDS addresses equal the forward transform's, and as
         // common subexpressions they would stay alive across the filter phase, where register pressure peaks
@@ -1812,7 +1834,11 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
             Core::template run<SEQ, true>(v, grp_lds, tw_fwd, bases, ti);
         }
     }
+    FDR_STAMP(4);
     if (active) tile_store<Core>(data, loff, v);
+    FDR_STAMP(5);
+    FDR_STAMP_WAIT_VM();
+    FDR_STAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -693,6 +693,49 @@ def test_one_gpu_shard_of_config5_every_image(fdr, oracle):
         assert mx <= TOL and rel <= TOL, (i, mx, rel)
 
 
+def test_config5_partition_over_eight_workers_every_image(fdr, oracle):
+    """BASELINE config 5's OWN partition -- 512 x 2048^2 over G = 8, 64 images per worker by calculate_distribution
+    (fft/fft_mpi.cpp:89-100) -- through fdr_batch_run with eight device entries.  The test box has one GPU, so all eight
+    workers (host threads with their own plans and streams) share device 0; host images go in (the copy path, pipelined
+    per worker) and ALL 512 results must carry the bits of the one-image-at-a-time path.  Also the device-resident
+    synthetic run of the same partition (what bench / a C caller would time): per-worker image counts, the start line
+    (every worker's timed region begins after the slowest one's set-up) and the checksum."""
+    import torch
+    S, B, G = 2048, 512, 8
+    P = S * S
+    d_in = torch.empty((B, S, S), dtype=torch.float32, device="cuda")
+    fdr.synth_image_dev(d_in.data_ptr(), B * P, 0x5EED0005)
+    d_one = torch.empty_like(d_in)
+    s = torch.cuda.current_stream().cuda_stream
+    with fdr.Plan(S, S, fdr.MODE_FAST) as p:
+        p.set_psf_motion(50, 30.0, 0.01, stream=s)
+        for i in range(B):
+            p.wiener_dev(d_in[i].data_ptr(), S, S, S, d_one[i].data_ptr(), S, stream=s)
+    torch.cuda.synchronize()
+    imgs = d_in.cpu().numpy()
+    del d_in
+    st, outs = fdr.batch_run([0] * G, S, S, B, mode=fdr.MODE_FAST, psf_size=50, psf_angle=30.0, imgs=imgs)
+    assert st["images"] == [64] * G and st["first"] == [64 * g for g in range(G)] and st["status"] == [0] * G, st
+    assert st["images_done"] == B and st["filter_path"] == "local"
+    bad = []
+    for lo in range(0, B, 64):  # compared on the device, a worker's shard at a time
+        got = torch.from_numpy(outs[lo:lo + 64]).cuda()
+        bad += [lo + i for i in range(64) if not bool(torch.equal(got[i], d_one[lo + i]))]
+        del got
+    assert not bad, ("images that differ from the one-by-one path", bad[:16], len(bad))
+    ref_sum = [float(d_one[64 * g:64 * (g + 1)].to(torch.float64).sum().item()) for g in range(G)]
+    for g in range(G):
+        assert abs(st["checksum"][g] - ref_sum[g]) <= 1e-9 * abs(ref_sum[g]), (g, st["checksum"][g], ref_sum[g])
+    del imgs, outs
+    # the same partition device resident and synthetic, as a C caller of the batched mode runs it
+    st2, _ = fdr.batch_run([0] * G, S, S, B, mode=fdr.MODE_FAST, psf_size=50, psf_angle=30.0, seed=0x5EED0005, steps=2, warmup=1)
+    assert st2["images"] == [64] * G and st2["status"] == [0] * G and st2["images_done"] == 2 * B and st2["mpixels_per_s"] > 0
+    for g in range(G):
+        assert abs(st2["checksum"][g] - ref_sum[g]) <= 1e-9 * abs(ref_sum[g]), (g, st2["checksum"][g], ref_sum[g])
+    # start line: no worker's timed region is longer than the common wall time (they all start together)
+    assert max(st2["elapsed_ms"]) <= st2["wall_ms"] * 1.0001 + 1e-3, st2
+
+
 def test_filter_block_export_import_between_plans(fdr, oracle):
     """fdr_plan_export_filter_dev / fdr_plan_import_filter_dev (what bench.py --bcast-filter moves with dist.broadcast):
     a plan that IMPORTS another plan's filter block restores the same bits as the plan that built it from the PSF, in both

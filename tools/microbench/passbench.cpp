@@ -110,6 +110,33 @@ int main(int argc, char** argv) {
         sum_us += us;
     }
     std::printf("  sum of passes %.2f us/image = %.0f Mpixels/s single stream\n", sum_us, P / sum_us);
+    {   // -DFDR_DEBUG_STAMPS builds: phase stamps of pass B' (wave 0 of every workgroup of the LAST launch), shader-clock ticks
+        int (*read_stamps)(unsigned long long*, size_t) = nullptr;
+        *(void**)(&read_stamps) = dlsym(h, "fdr_debug_read_stamps");
+        if (read_stamps) {
+            const int ntiles = S / 8, wgs = std::min(8192, ntiles * std::max(1, group));
+            std::vector<unsigned long long> stp((size_t)8192 * 8);
+            if (read_stamps(stp.data(), stp.size()) == 0) {
+                static const char* ph[6] = {"tile load (issue + landed)", "forward transforms", "filter W (loads + products)", "inverse transforms", "stores issued", "stores retired"};
+                double acc[6] = {0}, life = 0;
+                unsigned long long t_first = ~0ull, t_last = 0;
+                int cnt = 0;
+                for (int b = 0; b < wgs; ++b) {
+                    const unsigned long long* q = &stp[(size_t)b * 8];
+                    if (q[0] == 0 || q[6] <= q[0]) continue;
+                    for (int i = 0; i < 6; ++i) acc[i] += (double)(q[i + 1] - q[i]);
+                    life += (double)(q[6] - q[0]);
+                    t_first = std::min(t_first, q[0]); t_last = std::max(t_last, q[6]);
+                    ++cnt;
+                }
+                if (cnt) {
+                    std::printf("  pass B' phase stamps (wave 0 of %d workgroups of the last launch; counter ticks, mean per workgroup):\n", cnt);
+                    for (int i = 0; i < 6; ++i) std::printf("    %-30s %9.0f  (%4.1f %%)\n", ph[i], acc[i] / cnt, 100.0 * acc[i] / life);
+                    std::printf("    %-30s %9.0f ; first start to last end of the launch %llu ticks\n", "workgroup lifetime", life / cnt, t_last - t_first);
+                }
+            }
+        }
+    }
 
     // throughput with the requested streams x group
     FCK(api.set_batching(plan, streams, group));
