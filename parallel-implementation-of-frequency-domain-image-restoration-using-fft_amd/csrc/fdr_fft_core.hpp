@@ -38,6 +38,23 @@ __device__ __forceinline__ void fdr_jitter(unsigned salt) {
 #define FDR_JITTER(salt) ((void)0)
 #endif
 
+// Stamps inside a transform (timing-only debug builds, -DFDR_DEBUG_STAMPS): shader-clock counter of thread 0 after every
+// butterfly step and every exchange of the column pass's core (16 values x 4 columns per thread), slots 8.. (forward) and
+// 16.. (inverse) of the workgroup's 32-entry record; see fdr_panel.hip.  The values are pinned at each stamp.
+#ifdef FDR_DEBUG_STAMPS
+static __device__ unsigned long long fdr_dbg_stamps[8192 * 32];
+#define FDR_CORE_STAMP(cond, slot, v)                                                                                    \
+    do {                                                                                                                 \
+        if constexpr (cond) {                                                                                            \
+            _Pragma("unroll") for (int b_ = 0; b_ < B; ++b_) _Pragma("unroll") for (int s_ = 0; s_ < V; ++s_)          \
+                asm volatile("" : "+v"(v[b_][s_].x), "+v"(v[b_][s_].y));                                              \
+            if (threadIdx.x == 0) fdr_dbg_stamps[((blockIdx.x + gridDim.x * blockIdx.y) & 8191) * 32 + (slot)] = __builtin_readcyclecounter(); \
+        }                                                                                                                \
+    } while (0)
+#else
+#define FDR_CORE_STAMP(cond, slot, v) ((void)0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // compile-time step plan for L = 2^LOGL: small radix first (so only radix-8 steps ever read a
 // padded layout), T = L/8 threads per transform.
@@ -553,9 +570,11 @@ struct FftCore {
     static __device__ __forceinline__ void steps_from(float2 (&v)[B][V], float2* lds, const float2* __restrict__ tw,
                                                       const Bases& bs, int tid) {
         butterflies<J, INV>(v, tw, bs, tid);
+        FDR_CORE_STAMP((B == 4 && LOGV == 4), (INV ? 16 : 8) + 2 * J, v);
         if constexpr (J + 1 < S) {
             if constexpr (SWAP0 && J == 0) exchange_swap(v);
             else exchange<J, SEQ0>(v, lds, tid);
+            FDR_CORE_STAMP((B == 4 && LOGV == 4), (INV ? 16 : 8) + 2 * J + 1, v);
             steps_from<J + 1, SEQ0, INV>(v, lds, tw, bs, tid);
         }
     }

@@ -115,24 +115,40 @@ int main(int argc, char** argv) {
         *(void**)(&read_stamps) = dlsym(h, "fdr_debug_read_stamps");
         if (read_stamps) {
             const int ntiles = S / 8, wgs = std::min(8192, ntiles * std::max(1, group));
-            std::vector<unsigned long long> stp((size_t)8192 * 8);
+            std::vector<unsigned long long> stp((size_t)8192 * 32);
             if (read_stamps(stp.data(), stp.size()) == 0) {
                 static const char* ph[6] = {"tile load (issue + landed)", "forward transforms", "filter W (loads + products)", "inverse transforms", "stores issued", "stores retired"};
-                double acc[6] = {0}, life = 0;
+                double acc[6] = {0}, life = 0, inner[2][8] = {{0}};
                 unsigned long long t_first = ~0ull, t_last = 0;
                 int cnt = 0;
                 for (int b = 0; b < wgs; ++b) {
-                    const unsigned long long* q = &stp[(size_t)b * 8];
+                    const unsigned long long* q = &stp[(size_t)b * 32];
                     if (q[0] == 0 || q[6] <= q[0]) continue;
                     for (int i = 0; i < 6; ++i) acc[i] += (double)(q[i + 1] - q[i]);
                     life += (double)(q[6] - q[0]);
+                    // inside the transforms: slot 8 + 2 J = butterflies of step J done, 8 + 2 J + 1 = exchange J done (16.. inverse)
+                    for (int d = 0; d < 2; ++d) {
+                        unsigned long long prev = d == 0 ? q[1] : q[3];
+                        for (int i = 0; i < 8; ++i) {
+                            const unsigned long long t = q[8 + 8 * d + i];
+                            if (t == 0 || t < prev) break;
+                            inner[d][i] += (double)(t - prev);
+                            prev = t;
+                        }
+                    }
                     t_first = std::min(t_first, q[0]); t_last = std::max(t_last, q[6]);
                     ++cnt;
                 }
                 if (cnt) {
                     std::printf("  pass B' phase stamps (wave 0 of %d workgroups of the last launch; counter ticks, mean per workgroup):\n", cnt);
                     for (int i = 0; i < 6; ++i) std::printf("    %-30s %9.0f  (%4.1f %%)\n", ph[i], acc[i] / cnt, 100.0 * acc[i] / life);
-                    std::printf("    %-30s %9.0f ; first start to last end of the launch %llu ticks\n", "workgroup lifetime", life / cnt, t_last - t_first);
+                    std::printf("    %-30s %9.0f\n", "workgroup lifetime", life / cnt);
+                    (void)t_first; (void)t_last;
+                    for (int d = 0; d < 2; ++d) {
+                        std::printf("    inside the %s transforms (4 columns):", d == 0 ? "forward" : "inverse");
+                        for (int i = 0; i < 8 && inner[d][i] > 0; ++i) std::printf("  %s%d %.0f", (i & 1) ? "exchange" : "butterflies", i / 2, inner[d][i] / cnt);
+                        std::printf("\n");
+                    }
                 }
             }
         }
