@@ -1498,30 +1498,6 @@ __device__ __forceinline__ void tile_store(float2* __restrict__ ubase, unsigned 
         }
 }
 
-// Persistent column pass: every row of the finished tile is stored and the SAME registers are refilled at once with that row
-// of the workgroup's next tile (a store has handed its data over when it issues), so the next tile's read latency runs
-// behind this tile's store phase instead of after it.  Slots in last-step result order; the caller renames them to the
-// first-step operand order (FftCore::permute_out_to_in).
-template <class Core>
-__device__ __forceinline__ void tile_store_load(float2* __restrict__ ubase, const float2* __restrict__ nbase, unsigned loff, float2 (&d)[4][Core::V]) {
-    const unsigned lo = loff * 8u;
-#pragma unroll
-    for (int u = 0; u < Core::NUL; ++u)
-#pragma unroll
-        for (int q = 0; q < Core::RHOL; ++q) {
-            const int s = u * Core::RHOL + q;
-            const unsigned uoff = (unsigned)(((q << Core::LOGOUT) + u * Core::T) * 4);
-#ifdef FDR_DEBUG_SKIP_MEM
-            if (d[0][s].x != 1.2345e-30f) continue;
-#endif
-            gstore32(uniform_gptr(ubase + uoff), lo, d[0][s], d[1][s], d[2][s], d[3][s]);
-            asm volatile("" ::: "memory");
-            const gchar* nb = uniform_gptr(nbase + uoff);
-            FDR_GLOAD32(nb, lo, d[0][s], d[1][s], d[2][s], d[3][s]);
-            asm volatile("" ::: "memory");
-        }
-}
-
 // Reads every register of a prefetched set through an empty asm, so the compiler places the wait for those loads HERE
 // and treats them as landed afterwards.  Used right before the tile's stores are issued: vmcnt counts loads and
 // stores in issue order, so a wait for the spectrum prefetch placed after the stores (where the values are first
@@ -1689,34 +1665,23 @@ struct Panel16Geom {
     static constexpr int THREADS = T * G;
 };
 
-#ifndef FDR_B16_WGS
-#define FDR_B16_WGS 2   // workgroups per CU the column pass is compiled for (A/B builds: 3 with FDR_B16_NBUF = 1)
-#endif
-#ifndef FDR_B16_NBUF
-#define FDR_B16_NBUF 2  // exchange buffers of the column pass
-#endif
-#ifndef FDR_B16_PERS
-#define FDR_B16_PERS 0  // 1: persistent workgroups (FDR_B16_WGS per CU), the next tile's loads issued row by row behind this tile's stores
-#endif
 template <int LOGM>
-__global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, FDR_B16_WGS) void fft_cols_panel_fused16_kernel(
+__global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_fused16_kernel(
     const PanelBatch pb, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const unsigned pstride,
     const int npanels, const int ntiles, const int packed0, const int img_shift) {
     using St = Steps<LOGM, 4>;
     constexpr int G = Panel16Geom<LOGM>::G, T = St::T, M = St::L, V = 16;
-    using Core = FftCore<LOGM, 4, FDR_B16_NBUF, typename std::conditional<(LOGM == 12 && !FDR_COLS12_PACKED), PolicyFastScalar, PolicyFast>::type, 4,
+    using Core = FftCore<LOGM, 4, 2, typename std::conditional<(LOGM == 12 && !FDR_COLS12_PACKED), PolicyFastScalar, PolicyFast>::type, 4,
                          (St::lr(0) == 1 && T >= 64 && FDR_SWAP0)>;  // see PolicyFastScalar; 8192 points: wave-local first exchange
-    __shared__ float2 lds[G * FDR_B16_NBUF * St::BUF];
+    __shared__ float2 lds[G * 2 * St::BUF];
     const int g = G == 1 ? 0 : (int)(threadIdx.x >> St::LOGT);
-    const int tid0 = Core::thread_index(threadIdx.x & (T - 1));
-    float2* grp_lds = lds + g * FDR_B16_NBUF * St::BUF;
+    const int tid = Core::thread_index(threadIdx.x & (T - 1));
+    float2* grp_lds = lds + g * 2 * St::BUF;
     // Two mappings of workgroups to (tile, image), both free of integer divisions (which would run on the VALU and drag
     // every tile address into VGPRs).  img_shift < 0: grid (ntiles, images).  Otherwise (2, 4 or 8 images, tiles a multiple
     // of 8): a flat grid in which the workgroups that share a tile -- and so its slice of the filter W -- are neighbours
     // on the SAME XCD (workgroup b lands on XCD b % 8), so W crosses the fabric once per tile, not once per image.
-    // FDR_B16_PERS (flat grids only): the grid holds as many workgroups as the chip keeps resident and every workgroup walks
-    // over tiles b, b + gridDim.x, ... of ITS image (the stride is a multiple of 8 << img_shift, so XCD slot and image stay).
-    int img, tl, bcur = (int)blockIdx.x;
+    int img, tl;
     if (img_shift < 0) { img = blockIdx.y; tl = blockIdx.x; }
     else {
         const int b = blockIdx.x, j = b >> 3;
@@ -1725,12 +1690,12 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, FDR_B16_WGS) void fft_c
     }
     const bool active = tl * G + g < npanels;
     const size_t tbase = (size_t)(tl * G) * pstride;
-    float2* data = pick_image(pb.data, img) + tbase;
-    const float2* tfilt = filt + tbase;
-    (void)bcur;
+    float2* __restrict__ data = pick_image(pb.data, img) + tbase;
+    const float2* __restrict__ tfilt = filt + tbase;
+    const unsigned loff = (active ? (unsigned)g : 0u) * pstride + (unsigned)tid * 4u;
 
     typename Core::Bases bases;
-    Core::init_bases(bases, tw_fwd, tid0);
+    Core::init_bases(bases, tw_fwd, tid);
     // 8192 points: the tile fills 128 of the 256 registers a lane has and the filter phase needs the rest, so the hoisted
     // twiddle bases (one float2 per radix-16 step) did not survive it -- hipcc spilled them in the forward transform and
     // reloaded them from scratch in the inverse (3 x 8 bytes per lane: 28 bytes of scratch, ~50 MB of HBM traffic per
@@ -1740,7 +1705,7 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, FDR_B16_WGS) void fft_c
     __shared__ float2 parked[kParkBases ? (St::S - 1) * T : 1];
     if constexpr (kParkBases) {
 #pragma unroll
-        for (int j = 1; j < St::S; ++j) parked[(j - 1) * T + tid0] = bases.b[j][0];  // (the logical index: one slot per thread)
+        for (int j = 1; j < St::S; ++j) parked[(j - 1) * T + tid] = bases.b[j][0];  // (the logical index: one slot per thread)
     }
 
     // (Delaying the workgroup that landed in the odd wave slots by half a load phase, so that the two workgroups of
@@ -1764,21 +1729,7 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, FDR_B16_WGS) void fft_c
     // traffic alone -- four 64 MiB images in place plus one shared 64 MiB filter -- in 94-106 us, 24-26.5 us per image.)
     float2 v[4][V];
     FDR_STAMP(0);
-    {
-        const unsigned loff0 = (active ? (unsigned)g : 0u) * pstride + (unsigned)tid0 * 4u;
-        tile_load<Core, false>(data, loff0, 1u, v);
-    }
-#if FDR_B16_PERS
-  for (;;) {
-#endif
-    // (persistent form: an opaque copy of the thread index per tile -- nothing derived from it is loop invariant to the
-    // optimiser, so exchange and filter addresses are computed where they are used, as in the one-tile form, instead of
-    // being hoisted out of the loop and spilled)
-    int tid = tid0;
-#if FDR_B16_PERS
-    asm volatile("" : "+v"(tid));
-#endif
-    const unsigned loff = (active ? (unsigned)g : 0u) * pstride + (unsigned)tid * 4u;
+    tile_load<Core, false>(data, loff, 1u, v);
     FDR_STAMP_WAIT_VM();
     FDR_STAMP_PIN(v);
     FDR_STAMP(1);
@@ -1892,29 +1843,10 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, FDR_B16_WGS) void fft_c
     }
     FDR_STAMP_PIN(v);
     FDR_STAMP(4);
-#if FDR_B16_PERS
-    {
-        const int bn = bcur + (int)gridDim.x;
-        if (img_shift >= 0 && bn < (ntiles << img_shift)) {  // uniform: the workgroup's next tile, same image, same XCD slot
-            const int tln = tl + (((int)gridDim.x >> (3 + img_shift)) << 3);
-            const size_t nb = (size_t)(tln * G) * pstride;
-            float2* data_n = pick_image(pb.data, img) + nb;
-            tile_store_load<Core>(data, data_n, loff, v);
-            Core::permute_out_to_in(v);  // (result order of the inverse -> operand order of the forward transform: a renaming)
-            bcur = bn; tl = tln; data = data_n; tfilt = filt + nb;
-            __syncthreads();  // the exchange buffers (and the packed column's hand-over) of this tile are done with
-            continue;
-        }
-    }
-#endif
     if (active) tile_store<Core>(data, loff, v);
     FDR_STAMP(5);
     FDR_STAMP_WAIT_VM();
     FDR_STAMP(6);
-#if FDR_B16_PERS
-    break;
-  }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2077,14 +2009,7 @@ static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const floa
             using G16 = Panel16Geom<LOGM>;
             const int nt16 = (npanels + G16::G - 1) / G16::G;
             const int ishift = FDR_SHARE_W && (nt16 % 8 == 0) ? (pb.nimg == 2 ? 1 : pb.nimg == 4 ? 2 : pb.nimg == 8 ? 3 : -1) : -1;
-            dim3 grid16 = ishift < 0 ? dim3(nt16, pb.nimg) : dim3(nt16 * pb.nimg);
-#if FDR_B16_PERS
-            if (ishift >= 0) {  // resident workgroups only (FDR_B16_WGS per CU), a multiple of 8 << ishift; each walks over its tiles
-                const int unit = 8 << ishift;
-                int res = ((a.num_cu > 0 ? a.num_cu : 256) * FDR_B16_WGS / unit) * unit;
-                if (res >= unit && (int)grid16.x > res) grid16 = dim3(res);
-            }
-#endif
+            const dim3 grid16 = ishift < 0 ? dim3(nt16, pb.nimg) : dim3(nt16 * pb.nimg);
             hipLaunchKernelGGL((fft_cols_panel_fused16_kernel<LOGM>), grid16, dim3(G16::THREADS), 0, s, pb, a.filt, tw,
                                (unsigned)ps, npanels, nt16, a.packed0, ishift);
         } else {                     // short columns: persistent radix-8 kernel, register double-buffered
