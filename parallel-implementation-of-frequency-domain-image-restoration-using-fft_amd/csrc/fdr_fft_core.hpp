@@ -138,7 +138,10 @@ struct PolicyFast {
         // v_pk_fma_f32 (left to itself hipcc packs only about half of them; the rest are six scalar v_fma each):
         // 30 % fewer VALU instructions per transform, 1.37 -> 1.03 us per 4096-point transform per CU.  The rotated
         // twiddle (-w.y, w.x) is a register pair per twiddle; building it from operand modifiers instead (negated
-        // broadcast of v.y) costs a v_mov per butterfly and was slower.
+        // broadcast of v.y) costs a v_mov per butterfly and was slower.  (Round 4: the three instructions written out as
+        // inline asm with op_sel / neg_lo on the twiddle doing the rotation -- no second pair, 254 -> 238 registers in pass B' --
+        // measured equal within noise, 33.8 / 35.3 vs 34.3 / 34.9 us per 4096^2 image: the passes are not bound by their VALU
+        // work; hipcc also pads every inline-asm def-use pair closer than three instructions with an s_nop.  Not kept.)
         const v2f uu = {u.x, u.y}, vx = {v.x, v.x}, vy = {v.y, v.y}, ww = {w.x, w.y}, wr = {-w.y, w.x};
         const v2f t = __builtin_elementwise_fma(vy, wr, uu);   // (u.x - v.y w.y, u.y + v.y w.x)
         const v2f a = __builtin_elementwise_fma(vx, ww, t);    // (.. + v.x w.x, .. + v.x w.y)

@@ -17,12 +17,14 @@ def main():
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29571")
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", FDR_DIST_SINGLE="1", FDR_DIST_TIMEOUT_S="120")
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    dist.init_process_group(backend="nccl", rank=0, world_size=1)
     batch = importlib.import_module(PKG + ".batch")
-    comm = batch.Comm(backend="nccl", device=dev)  # WORLD_SIZE is 1 in the environment: attach the group by hand
-    comm.dist, comm.world, comm.rank = dist, 1, 0
+    # Comm's OWN set-up, as bench.py --gpus N runs it on every rank: init_process_group(backend="nccl", device_id=cuda:0,
+    # timeout=...), collectives through the guard that turns a failure into a message and a non-zero exit
+    comm = batch.Comm(backend="nccl", device=dev)
+    assert comm.dist is not None and dist.is_initialized() and dist.get_backend() == "nccl"
     comm.barrier()
     mx, mn = comm.allreduce_max(1.25), comm.allreduce_min(-3.5)
     sm = comm.allreduce_sum([1, 2.5, 4])

@@ -236,3 +236,26 @@ def test_plan_cache_of_the_cpp_surface_is_bounded_and_released():
     assert "~PlanCache() { clear(); }" in src
     for name in ("release_cached_plans", "set_plan_cache_capacity", "plan_cache_capacity"):
         assert re.search(r"inline \w+ %s\(" % name, src), name
+
+
+def test_collective_failure_is_loud_not_a_hang(tmp_path):
+    """batch.Comm: a collective that cannot complete (the peer rank is gone) ends the process with a one-line message and
+    exit code 13 inside the deadline, so that a launcher stops the job instead of waiting on it (first contact with an
+    8-GPU node must not be able to hang: VERDICT r03 next #2)."""
+    import socket
+    import time
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", FDR_DIST_TIMEOUT_S="20")
+    worker = os.path.join(ROOT, "tests", "_dist_fail_worker.py")
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, worker], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180) for p in procs]
+    dt = time.time() - t0
+    assert procs[1].returncode == 0
+    assert procs[0].returncode == 13, (procs[0].returncode, outs[0])
+    assert "fdr.batch: rank 0/2: barrier failed (backend gloo)" in outs[0][1], outs[0][1]
+    assert "UNREACHABLE" not in outs[0][0]
+    assert dt < 120, dt
