@@ -126,6 +126,7 @@ struct fdr_plan {
     int device = 0, M = 0, N = 0, logM = 0, logN = 0, mode = 0;
     unsigned flags = 0;
     bool simple = false;
+    bool big = false;  // a power-of-two dimension above 8192: simple sequence with the long row pass (fdr_aux.hip)
     int num_cu = 256;
     bool tables_only = false;  // FDR_FLAG_TABLES_ONLY: no workspaces, slab primitives only
     bool generic = false;  // FDR_FLAG_ANY_SIZE with a non-power-of-two dimension: naive DFT along that dimension
@@ -333,29 +334,55 @@ int upload(float2** dst, const std::vector<float2>& v) {
 }
 
 // unscaled 2-D transform in place on d (M x N), rows then columns as fft/fft_serial.cpp:113-139
+// `rows` transforms of L = 2^logl > 8192 points held contiguously in `buf`, `tmp` of the same size free: see fdr_aux.hip
+// (long_gather_kernel).  twf / twi: the forward / inverse tables of the plan's mode for length L (their first 8191 entries
+// are the tables of the 8192-point transform: build_twiddles stores stage `len` at offset len/2 - 1).  Result in `buf`.
+hipError_t long_rows_dev(float2* buf, float2* tmp, size_t rows, int L, int logl, int mode, bool inverse, const float2* twf, const float2* twi,
+                         hipStream_t s) {
+    const int logs = logl - kMaxLdsLog, L0 = 1 << kMaxLdsLog;
+    if (rows << logs > (size_t)0x7fffffff) return hipErrorInvalidValue;  // (the row kernels count rows in an int)
+    hipError_t e = launch_long_gather(buf, tmp, rows, L, logs, s);
+    if (e != hipSuccess) return e;
+    RowArgs ra{};
+    ra.src_c = tmp; ra.dst_c = tmp; ra.M = (int)(rows << logs);
+    // the register kernels: parity -> the table of the direction; fast -> the forward table (they conjugate it)
+    e = launch_rows(kMaxLdsLog, mode, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, inverse, ra, mode == FDR_MODE_FAST ? twf : (inverse ? twi : twf), s);
+    if (e != hipSuccess) return e;
+    for (int half = L0; half < L; half <<= 1) {  // in place in `tmp` (a butterfly reads and writes its own pair), the last one into `buf`
+        const bool last = (half << 1) == L;
+        e = launch_long_stage(tmp, last ? buf : tmp, rows, L, half, inverse ? twi : twf, mode, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 int dft2d_dev(fdr_plan* p, float2* d, float2* work2, bool inverse, hipStream_t s) {
     const float2* twr = inverse ? p->tw_row_i : p->tw_row_f;
     const float2* twc = inverse ? p->tw_col_i : p->tw_col_f;
     if (p->simple) {  // the reference's own sequence: rows, transpose, rows, transpose (fft/fft_serial.cpp:113-139)
         // one row pass over `rows` rows of length L held in `buf`, `tmp` free: radix-2 for powers of two, else the naive
         // DFT (transform_row_inplace, :100-101), which runs out of place and is copied back
-        auto row_pass = [&](float2* buf, float2* tmp, int rows, int L, int logl, const float2* tw, const float2* naive) -> int {
+        auto row_pass = [&](float2* buf, float2* tmp, int rows, int L, int logl, const float2* tw, const float2* twf, const float2* twi,
+                            const float2* naive) -> int {
             if (naive) {
                 FDR_HIP(launch_dft_naive_rows(buf, tmp, rows, L, naive, inverse ? 1 : 0, s));
                 FDR_HIP(hipMemcpyAsync(buf, tmp, (size_t)rows * L * sizeof(float2), hipMemcpyDeviceToDevice, s));
-            } else if (p->generic && L >= 8) {  // register kernels, in place (parity arithmetic: direction-specific table)
+            } else if (logl > kMaxLdsLog) {  // more than 8192 points: 8192-point blocks + global radix-2 stages
+                FDR_HIP(long_rows_dev(buf, tmp, (size_t)rows, L, logl, p->mode, inverse, twf, twi, s));
+            } else if ((p->generic || p->big) && L >= 8) {
+                // register kernels, in place (parity: the table of the direction; fast: the forward table, they conjugate it)
                 RowArgs ra{};
                 ra.src_c = buf; ra.dst_c = buf; ra.M = rows;
-                FDR_HIP(launch_rows(logl, FDR_MODE_PARITY, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, inverse, ra, tw, s));
+                FDR_HIP(launch_rows(logl, p->mode, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, inverse, ra, p->mode == FDR_MODE_FAST ? twf : tw, s));
             } else {
                 FDR_HIP(launch_simple_rows(buf, rows, L, logl, tw, p->mode, s));
             }
             return FDR_OK;
         };
-        int rc = row_pass(d, work2, p->M, p->N, p->logN, twr, p->naive_row);
+        int rc = row_pass(d, work2, p->M, p->N, p->logN, twr, p->tw_row_f, p->tw_row_i, p->naive_row);
         if (rc != FDR_OK) return rc;
         FDR_HIP(launch_transpose(d, work2, p->M, p->N, s));
-        rc = row_pass(work2, d, p->N, p->M, p->logM, twc, p->naive_col);
+        rc = row_pass(work2, d, p->N, p->M, p->logM, twc, p->tw_col_f, p->tw_col_i, p->naive_col);
         if (rc != FDR_OK) return rc;
         FDR_HIP(launch_transpose(work2, d, p->N, p->M, s));
         return FDR_OK;
@@ -648,7 +675,10 @@ static int plan_create_impl(fdr_plan* p, int device, int M, int N, int mode, uns
     if (p->generic) p->mode = mode = FDR_MODE_PARITY;
     p->logM = fdr_is_pow2(M) ? ilog2(M) : -1;
     p->logN = fdr_is_pow2(N) ? ilog2(N) : -1;
-    p->simple = p->generic || (flags & FDR_FLAG_SIMPLE_PATH) != 0 || M < 8 || N < 8;
+    // dimensions above 8192 (one row no longer fits the LDS): the reference-shaped sequence rows / transpose / rows / transpose
+    // with the long row pass (fdr_aux.hip, long_gather_kernel) -- as the serial path, correct at any power of two and slower
+    p->simple = p->generic || (flags & FDR_FLAG_SIMPLE_PATH) != 0 || M < 8 || N < 8 || M > (1 << kMaxLdsLog) || N > (1 << kMaxLdsLog);
+    p->big = (fdr_is_pow2(M) && M > (1 << kMaxLdsLog)) || (fdr_is_pow2(N) && N > (1 << kMaxLdsLog));
     p->panel = mode == FDR_MODE_FAST && !p->simple;
     {
         int cus = 0;
@@ -702,7 +732,8 @@ int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan
         if ((!fdr_is_pow2(M) && M > kMaxNaiveLen) || (!fdr_is_pow2(N) && N > kMaxNaiveLen))
             return fail(FDR_ERR_ARG, "fdr_plan_create: non-power-of-two dimension above 4096 (naive-DFT twiddle table)");
     }
-    if (M > 8192 || N > 8192) return fail(FDR_ERR_ARG, "fdr_plan_create: dimension above 8192 (one row must fit LDS)");
+    if (M > (1 << kMaxLongLog) || N > (1 << kMaxLongLog))
+        return fail(FDR_ERR_ARG, "fdr_plan_create: dimension above 32768");
     FDR_HIP(hipSetDevice(device));
     // registered behind the first HIP call, i.e. after the HIP runtime's own exit handlers: it runs BEFORE them
     static std::once_flag exit_hook;
@@ -1263,8 +1294,27 @@ int fdr_fft1d_c2c(float* data_host, int n, int inverse, int mode) {
     if (mode != FDR_MODE_PARITY && mode != FDR_MODE_FAST) return fail(FDR_ERR_ARG, "fdr_fft1d_c2c: unknown mode");
     if (n <= 1) return FDR_OK;                                        // fft/fft_serial.cpp:43
     if (!fdr_is_pow2(n)) return fdr_dft_naive_c2c(data_host, n, inverse);  // fft/fft_serial.cpp:100-101
-    if (n > 8192) return fail(FDR_ERR_ARG, "fdr_fft1d_c2c: power-of-two length above 8192 (one row must fit LDS)");
+    if (n > (1 << kMaxLongLog)) return fail(FDR_ERR_ARG, "fdr_fft1d_c2c: power-of-two length above 32768");
     std::vector<float2> t;
+    if (n > (1 << kMaxLdsLog)) {  // 8192-point blocks + global stages (fdr_aux.hip): both tables of the mode
+        std::vector<float2> ti;
+        build_twiddles(n, mode, false, t);
+        build_twiddles(n, mode, true, ti);
+        float2 *twf = nullptr, *twi = nullptr, *d = nullptr, *tmp = nullptr;
+        const size_t bytes = (size_t)n * sizeof(float2), tb = t.size() * sizeof(float2);
+        hipError_t e = hipMalloc((void**)&twf, tb);
+        if (e == hipSuccess) e = hipMalloc((void**)&twi, tb);
+        if (e == hipSuccess) e = hipMalloc((void**)&d, bytes);
+        if (e == hipSuccess) e = hipMalloc((void**)&tmp, bytes);
+        if (e == hipSuccess) e = hipMemcpy(twf, t.data(), tb, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(twi, ti.data(), tb, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d, data_host, bytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = long_rows_dev(d, tmp, 1, n, ilog2(n), mode, inverse != 0, twf, twi, nullptr);
+        if (e == hipSuccess) e = hipMemcpy(data_host, d, bytes, hipMemcpyDeviceToHost);
+        (void)hipFree(twf); (void)hipFree(twi); (void)hipFree(d); (void)hipFree(tmp);
+        FDR_HIP(e);
+        return FDR_OK;
+    }
     // the register kernels take the forward table in fast mode (they conjugate it); the simple kernel
     // (n < 8) and parity mode take the table of the requested direction
     build_twiddles(n, mode, (mode == FDR_MODE_FAST && n >= 8) ? false : (inverse != 0), t);

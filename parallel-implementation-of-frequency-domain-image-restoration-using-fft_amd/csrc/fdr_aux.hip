@@ -77,6 +77,56 @@ hipError_t launch_simple_rows(float2* data, int rows, int L, int logl, const flo
     return hipGetLastError();
 }
 
+// ---- transforms longer than one LDS row (L > 8192, a power of two): fft_serial::fft_radix2_inplace (fft/fft_serial.cpp:40-68)
+// takes any power of two.  Its stages len = 2 .. L0 act inside aligned blocks of L0 = 8192 positions of the bit-reversed
+// array, and block B of that array is the L0-point transform of the subsequence x[j S + bitrev(B)], S = L / L0: so the
+// subsequences are gathered into blocks (long_gather_kernel), every block runs through the ordinary L0-point row kernels as a
+// row of its own, and the remaining log2 S stages are plain butterflies over the whole row in global memory
+// (long_stage_kernel), with the SAME per-stage twiddle table and butterfly as every other stage -- parity mode stays
+// bit-identical to the serial recurrence.  Two extra passes over the data per transform plus one per stage above L0: the
+// serial path "only gets slow" beyond 8192 points, and so does this one.
+__global__ void long_gather_kernel(const float2* __restrict__ src, float2* __restrict__ dst, size_t rows, int L, int logs) {
+    const int S = 1 << logs, L0 = L >> logs;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over rows x L destination elements
+    if (idx >= rows * (size_t)L) return;
+    const size_t row = idx / (size_t)L;
+    const int pos = (int)(idx - row * (size_t)L);
+    const int B = pos / L0, j = pos - B * L0;
+    const int h = logs ? (int)(__brev((unsigned)B) >> (32 - logs)) : 0;
+    dst[idx] = src[row * (size_t)L + (size_t)j * S + h];
+}
+
+template <class Pol>
+__global__ void long_stage_kernel(const float2* src, float2* dst, size_t rows, int L, int half,  // (src may be dst: own pair only)
+                                  const float2* __restrict__ tw) {  // tw: table of the requested direction, all stages
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over rows x L/2 butterflies
+    const size_t per_row = (size_t)(L >> 1);
+    if (idx >= rows * per_row) return;
+    const size_t row = idx / per_row;
+    const int k = (int)(idx - row * per_row);
+    const int off = k & (half - 1);
+    const size_t ui = row * (size_t)L + (size_t)(((k - off) << 1) + off), vi = ui + (size_t)half;
+    float2 u = src[ui], v = src[vi];
+    Pol::bfly(u, v, tw[(half - 1) + off]);
+    dst[ui] = u;
+    dst[vi] = v;
+}
+
+hipError_t launch_long_gather(const float2* src, float2* dst, size_t rows, int L, int logs, hipStream_t s) {
+    const size_t n = rows * (size_t)L;
+    hipLaunchKernelGGL(long_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, L, logs);
+    return hipGetLastError();
+}
+
+hipError_t launch_long_stage(const float2* src, float2* dst, size_t rows, int L, int half, const float2* tw, int mode, hipStream_t s) {
+    const size_t n = rows * (size_t)(L >> 1);
+    if (mode == 0)
+        hipLaunchKernelGGL(long_stage_kernel<PolicyParity>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, L, half, tw);
+    else
+        hipLaunchKernelGGL(long_stage_kernel<PolicyFast>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, L, half, tw);
+    return hipGetLastError();
+}
+
 // ---- tile transpose through LDS (fft/fft_gpu.cu:153-164), 64-lane friendly 32x32 tile, +1 pad ----
 __global__ void transpose_kernel(const float2* __restrict__ src, float2* __restrict__ dst, int rows, int cols) {
     __shared__ float2 tile[32][33];

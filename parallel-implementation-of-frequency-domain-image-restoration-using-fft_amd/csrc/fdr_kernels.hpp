@@ -111,6 +111,12 @@ hipError_t launch_pad_real_to_complex(const float* src, int rows, int cols, int 
                                       hipStream_t s);
 hipError_t launch_simple_rows(float2* data, int rows, int L, int logl, const float2* tw, int mode, hipStream_t s);
 hipError_t launch_transpose(const float2* src, float2* dst, int rows, int cols, hipStream_t s);
+// transforms of more than 8192 points (fdr_aux.hip): subsequences gathered into 8192-point blocks, and one radix-2 stage
+// (butterfly distance `half`) over rows of length L in global memory; tw = table of the requested direction (both modes)
+constexpr int kMaxLdsLog = 13;    // longest transform the row / column kernels hold on chip
+constexpr int kMaxLongLog = 15;   // longest transform at all (32768 points)
+hipError_t launch_long_gather(const float2* src, float2* dst, size_t rows, int L, int logs, hipStream_t s);
+hipError_t launch_long_stage(const float2* src, float2* dst, size_t rows, int L, int half, const float2* tw, int mode, hipStream_t s);
 hipError_t launch_wiener_pointwise(float2* g, const float2* filt, size_t count, float K, int mode, hipStream_t s);
 hipError_t launch_make_filter_fast(const float2* H, float2* W, size_t count, float K, hipStream_t s);
 hipError_t launch_real_minmax(const float2* src, float* dst, int M, int N, int mm_rows, int mm_cols, float2* mm_part,

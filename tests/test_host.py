@@ -85,7 +85,8 @@ def test_argument_validation_precedes_any_device_work(fdr):
     assert fdr.lib.fdr_plan_create(0, 100, 64, 0, 0, ctypes.byref(h)) == -2  # FDR_ERR_NOT_POW2
     assert b"powers of two" in fdr.lib.fdr_last_error()
     assert fdr.lib.fdr_plan_create(0, 0, 64, 0, 0, ctypes.byref(h)) == -1
-    assert fdr.lib.fdr_plan_create(0, 64, 16384, 0, 0, ctypes.byref(h)) == -1  # above 8192
+    assert fdr.lib.fdr_plan_create(0, 64, 65536, 0, 0, ctypes.byref(h)) == -1  # above 32768 (8192 < n <= 32768: long row pass)
+    assert b"above 32768" in fdr.lib.fdr_last_error()
     assert fdr.lib.fdr_plan_create(0, 64, 64, 7, 0, ctypes.byref(h)) == -1     # unknown mode
     assert fdr.lib.fdr_plan_create(0, 64, 64, 0, 0, None) == -1
     assert fdr.lib.fdr_plan_destroy(None) == 0
