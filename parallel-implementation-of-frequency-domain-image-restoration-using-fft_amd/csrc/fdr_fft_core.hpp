@@ -183,28 +183,6 @@ struct PolicyFast {
     }
 };
 
-// The same three instructions written out, with the operand selectors of VOP3P doing the broadcasts of v.x / v.y AND the
-// rotation of the twiddle: (-w.y, w.x) is w read with its halves swapped and the low half negated (op_sel / neg_lo on source
-// 1), not a second register pair -- 16 registers less at the last stage of a radix-16 step (pass B' at 4096 points: 254 ->
-// 238).  Same products, same roundings, same bits.  Measured equal in time in kernels that fit their register budget anyway
-// (hipcc pads every inline-asm def-use pair closer than three instructions with an s_nop; the passes are not bound by their
-// VALU work), so only the kernels that need the registers use it.
-struct PolicyFastLean : PolicyFast {
-    static __device__ __forceinline__ void bfly(float2& u, float2& v, const float2 w) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        v2f uu = {u.x, u.y}, vv = {v.x, v.y}, t, a, b;
-        const v2f ww = {w.x, w.y};
-        //   t = (u.x - v.y w.y, u.y + v.y w.x);  a = t + (v.x w.x, v.x w.y);  b = 2 u - a
-        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=&v"(t) : "v"(vv), "v"(ww), "v"(uu));
-        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(a) : "v"(vv), "v"(ww), "v"(t));
-        asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(b) : "v"(uu), "v"(a));
-        u.x = a.x; u.y = a.y; v.x = b.x; v.y = b.y;
-#else
-        PolicyFast::bfly(u, v, w);
-#endif
-    }
-};
-
 // The same with scalar FMAs (what hipcc packs by itself): the 4096-point column pass keeps 128 data registers per lane,
 // where the extra register pair per rotated twiddle of the packed form spills (14 VGPRs, +15 % HBM traffic from scratch)
 // for no gain in time -- that kernel alone uses this variant.

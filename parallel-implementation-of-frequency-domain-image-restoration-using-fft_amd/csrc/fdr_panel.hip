@@ -1849,97 +1849,6 @@ __global__ __launch_bounds__(Panel16Geom<LOGM>::THREADS, 2) void fft_cols_panel_
     FDR_STAMP(6);
 }
 
-#ifdef FDR_EXP_HALF16
-// EXPERIMENT (register-count probe, round 4): half tiles -- a workgroup takes TWO of a panel's four columns (16 bytes per row
-// and lane), 16 values per thread and column: 64 data registers, one exchange buffer, compiled for 4 waves per SIMD.
-template <int LOGM>
-__global__ __launch_bounds__((Steps<LOGM, 4>::T), 4) void fft_cols_panel_half16_kernel(
-    const PanelBatch pb, const float2* __restrict__ filt, const float2* __restrict__ tw_fwd, const unsigned pstride, const int ntiles, const int img_shift) {
-    using St = Steps<LOGM, 4>;
-    constexpr int T = St::T, V = 16;
-    using Core = FftCore<LOGM, 2, 1, PolicyFastLean, 4, (St::lr(0) == 1 && T >= 64 && FDR_SWAP0)>;
-    __shared__ float2 lds[St::BUF];
-    const int tid = Core::thread_index(threadIdx.x & (T - 1));
-    const int b = blockIdx.x, half = (b >> 3) & 1, j = b >> 4;
-    const int img = j & ((1 << img_shift) - 1);
-    const int tl = ((j >> img_shift) << 3) | (b & 7);
-    if (tl >= ntiles) return;
-    const size_t tbase = (size_t)tl * pstride + (size_t)half * 2;
-    float2* data = pick_image(pb.data, img) + tbase;
-    const float2* tfilt = filt + tbase;
-    const unsigned lo = (unsigned)tid * 32u;  // bytes: one 32-byte panel row per thread index, this half's 16 bytes
-    typename Core::Bases bases;
-    Core::init_bases(bases, tw_fwd, tid);
-    float2 v[2][V];
-#pragma unroll
-    for (int u = 0; u < Core::NU0; ++u)
-#pragma unroll
-        for (int q = 0; q < Core::RHO0; ++q) {
-            const int s = u * Core::RHO0 + q;
-            const unsigned uoff = (unsigned)(((q << Core::LOGR0) + u * Core::T) * 4);
-            const gchar* ub = uniform_gptr(data + uoff);
-            const float4 x = *reinterpret_cast<const float4*>((const char*)ub + lo);
-            v[0][s] = make_float2(x.x, x.y); v[1][s] = make_float2(x.z, x.w);
-        }
-    Core::template run<0, false>(v, lds, tw_fwd, bases, tid);
-    // the twiddle bases of the inverse transform are fetched AGAIN here (L2 hits, in flight behind the filter's loads) from a
-    // thread index recomputed from threadIdx: nothing of the forward transform's address state stays alive across the filter
-    int ti = Core::thread_index((int)(threadIdx.x & (T - 1)));
-    asm volatile("" : "+v"(ti));
-    typename Core::Bases bases_i;
-    Core::init_bases(bases_i, tw_fwd, ti);
-    const unsigned lo2 = (unsigned)ti * 32u;
-    {
-#ifndef FDR_EXP_PC
-#define FDR_EXP_PC 4
-#endif
-        constexpr int PC = FDR_EXP_PC;
-        auto wload = [&](int h, float2 (&w)[PC][2]) {
-#pragma unroll
-            for (int i = 0; i < PC; ++i) {
-                const int s = PC * h + i, u = s / Core::RHOL, q = s % Core::RHOL;
-                const unsigned uoff = (unsigned)(((q << Core::LOGOUT) + u * Core::T) * 4);
-                const gchar* ub = uniform_gptr(tfilt + uoff);
-                const float4 x = *reinterpret_cast<const float4*>((const char*)ub + lo2);
-                w[i][0] = make_float2(x.x, x.y); w[i][1] = make_float2(x.z, x.w);
-            }
-        };
-        auto wmul = [&](int h, const float2 (&w)[PC][2]) {
-#pragma unroll
-            for (int i = 0; i < PC; ++i) {
-                const int s = PC * h + i;
-                v[0][s] = cmul_fma(v[0][s], w[i][0]);
-                v[1][s] = cmul_fma(v[1][s], w[i][1]);
-            }
-        };
-        float2 wa[PC][2], wb[PC][2];
-        wload(0, wa);
-#pragma unroll
-        for (int h = 0; h < V / PC; h += 2) {
-            asm volatile("" ::: "memory");
-            wload(h + 1, wb);
-            wmul(h, wa);
-            asm volatile("" ::: "memory");
-            if (h + 2 < V / PC) wload(h + 2, wa);
-            wmul(h + 1, wb);
-        }
-    }
-    Core::permute_out_to_in(v);
-    Core::template run<Core::SLOTS, true>(v, lds, tw_fwd, bases_i, ti);
-#pragma unroll
-    for (int u = 0; u < Core::NUL; ++u)
-#pragma unroll
-        for (int q = 0; q < Core::RHOL; ++q) {
-            const int s = u * Core::RHOL + q;
-            const unsigned uoff = (unsigned)(((q << Core::LOGOUT) + u * Core::T) * 4);
-            gchar* ub = uniform_gptr(data + uoff);
-            *reinterpret_cast<float4*>((char*)ub + lo2) = make_float4(v[0][s].x, v[0][s].y, v[1][s].x, v[1][s].y);
-        }
-}
-template __global__ void fft_cols_panel_half16_kernel<12>(const PanelBatch, const float2*, const float2*, const unsigned, const int, const int);
-template __global__ void fft_cols_panel_half16_kernel<13>(const PanelBatch, const float2*, const float2*, const unsigned, const int, const int);
-#endif
-
 // ---------------------------------------------------------------------------------------------
 // Pass B' for ONE small image (the single-image call of BASELINE config 2: M <= 2048).  The tile kernels above give a
 // 4-column tile to one thread group (64 threads at 1024 points): with a single image in flight that is 128 one-wave
@@ -2100,16 +2009,6 @@ static hipError_t launch_cols_panel_t(ColKind kind, const ColArgs& a, const floa
             using G16 = Panel16Geom<LOGM>;
             const int nt16 = (npanels + G16::G - 1) / G16::G;
             const int ishift = FDR_SHARE_W && (nt16 % 8 == 0) ? (pb.nimg == 2 ? 1 : pb.nimg == 4 ? 2 : pb.nimg == 8 ? 3 : -1) : -1;
-#ifdef FDR_EXP_HALF16
-            if constexpr (LOGM == 12 || LOGM == 13) {
-                const int hs = pb.nimg == 1 ? 0 : ishift;
-                if (hs >= 0 && nt16 % 8 == 0) {
-                    hipLaunchKernelGGL((fft_cols_panel_half16_kernel<LOGM>), dim3(nt16 * 2 * pb.nimg), dim3(G16::THREADS), 0, s, pb, a.filt, tw,
-                                       (unsigned)ps, nt16, hs);
-                    return hipGetLastError();
-                }
-            }
-#endif
             const dim3 grid16 = ishift < 0 ? dim3(nt16, pb.nimg) : dim3(nt16 * pb.nimg);
             hipLaunchKernelGGL((fft_cols_panel_fused16_kernel<LOGM>), grid16, dim3(G16::THREADS), 0, s, pb, a.filt, tw,
                                (unsigned)ps, npanels, nt16, a.packed0, ishift);
