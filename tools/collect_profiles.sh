@@ -38,6 +38,9 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -o cal -- ./too
 python3 bench.py --gpus 2 --backend gloo --one-device --size 2048 --batch 32 --steps 5 --warmup 2 --repeats 3 --no-psf-recompute > $OUT/two_rank_weak.log 2>&1; echo "two_rank_weak rc=$?" >> $OUT/status.txt
 python3 bench.py --gpus 2 --backend gloo --one-device --size 2048 --total-batch 63 --steps 5 --warmup 2 --repeats 3 --no-psf-recompute > $OUT/two_rank_strong.log 2>&1; echo "two_rank_strong rc=$?" >> $OUT/status.txt
 python3 bench.py --gpus 2 --backend gloo --one-device --size 2048 --batch 16 --steps 5 --warmup 2 --repeats 3 --no-psf-recompute --no-parity-leg --bcast-filter > $OUT/two_rank_bcast_filter.log 2>&1; echo "two_rank_bcast_filter rc=$?" >> $OUT/status.txt
+# config 5 exactly as the driver will call it, at the largest rank count this box admits (its process guard allows six GPU
+# processes and the launcher counts as one): five ranks on the one device, every image of every rank checked
+python3 bench.py --gpus 5 --backend gloo --one-device --size 2048 --total-batch 512 --steps 3 --warmup 1 --repeats 2 --no-psf-recompute --no-parity-leg > $OUT/five_rank_config5.log 2>&1; echo "five_rank_config5 rc=$?" >> $OUT/status.txt
 # BASELINE config 2 as written: ONE image per step, one stream, one image per launch (and the neighbouring sizes)
 for S in 512 1024 2048; do
   python3 bench.py --size $S --batch 1 --streams 1 --group 1 --steps 200 --warmup 20 --repeats 5 --no-cpu-baseline --no-psf-recompute --no-parity-leg > $OUT/single_image_$S.log 2>&1; echo "single_image_$S rc=$?" >> $OUT/status.txt
@@ -48,6 +51,11 @@ PKG="$GRAFT_REPO_ROOT/parallel-implementation-of-frequency-domain-image-restorat
 for S in 256 512 1024 2048; do tools/microbench/passbench $PKG/libfdr.so $S 8 20 1 1 >> $OUT/single_image_passbench.log 2>&1; done
 tools/microbench/passbench $PKG/libfdr.so 4096 24 10 2 4 >> $OUT/passbench_4096.log 2>&1
 tools/microbench/passbench $PKG/libfdr.so 8192 6 6 2 2 >> $OUT/passbench_8192.log 2>&1
+# pass B''s phase timeline (in-kernel stamps; needs the -DFDR_DEBUG_STAMPS build made beside the product build) and the bit-identical mode per pass
+if [ -f $PKG/build_dbg/libfdr_stamps.so ]; then
+  (tools/microbench/passbench $PKG/build_dbg/libfdr_stamps.so 4096 8 5 1 4; tools/microbench/passbench $PKG/build_dbg/libfdr_stamps.so 8192 4 3 1 2) > $OUT/passB_phase_stamps.log 2>&1
+fi
+(tools/microbench/passbench $PKG/libfdr.so 4096 8 5 3 1 0; tools/microbench/passbench $PKG/libfdr.so 8192 4 3 3 1 0) > $OUT/passbench_parity_mode.log 2>&1
 make -s -C tools/microbench rmw_bench
 (timeout -k 5 60 tools/microbench/rmw_bench 4 64 20; timeout -k 5 60 tools/microbench/rmw_bench 2 256 10) > $OUT/rmw_bench.log 2>&1; echo "rmw_bench rc=$?" >> $OUT/status.txt
 (timeout -k 5 60 tools/microbench/seam_bench 256 256 200; timeout -k 5 60 tools/microbench/seam_bench 128 256 200; timeout -k 5 60 tools/microbench/seam_bench 256 512 200) > $OUT/seam_bench.log 2>&1; echo "seam_bench rc=$?" >> $OUT/status.txt

@@ -149,7 +149,8 @@ def main():
             for r in stats:
                 if "fdr::" in r["Name"]:
                     w.writerow(r)
-    for name in ("single_image_passbench.log", "passbench_4096.log", "passbench_8192.log", "seam_bench.log", "rmw_bench.log"):
+    for name in ("single_image_passbench.log", "passbench_4096.log", "passbench_8192.log", "seam_bench.log", "rmw_bench.log", "passB_phase_stamps.log",
+                 "passbench_parity_mode.log"):
         pth = os.path.join(src, name)
         if os.path.exists(pth):
             txt = open(pth).read().replace(ROOT + "/", "")
@@ -157,7 +158,7 @@ def main():
             txt = re.sub(r"/tmp/code/[^ ]*/repo/", "", txt)
             open(os.path.join(dst, "%s_%s" % (tag, name)), "w").write(txt)
     for name in ("bench_line.json", "bench_line_streams1_4096.json", "bench_line_streams1_8192.json", "two_rank_weak.log", "two_rank_strong.log",
-                 "two_rank_bcast_filter.log", "single_image_512.log", "single_image_1024.log", "single_image_2048.log",
+                 "two_rank_bcast_filter.log", "five_rank_config5.log", "single_image_512.log", "single_image_1024.log", "single_image_2048.log",
                  "config5_one_gpu.log", "config2_size.log", "config4_size.log", "bench_raw_plane.log", "status.txt"):
         pth = os.path.join(src, name)
         if os.path.exists(pth):
