@@ -126,6 +126,7 @@ struct fdr_plan {
     int device = 0, M = 0, N = 0, logM = 0, logN = 0, mode = 0;
     unsigned flags = 0;
     bool simple = false;
+    bool ppar = false;  // parity operator on a PANEL-major complex intermediate (round 4): contiguous column tiles
     bool big = false;  // a power-of-two dimension above 8192: simple sequence with the long row pass (fdr_aux.hip)
     int num_cu = 256;
     bool tables_only = false;  // FDR_FLAG_TABLES_ONLY: no workspaces, slab primitives only
@@ -423,10 +424,10 @@ int set_psf_dev_impl(fdr_plan* p, const float* d_psf, int prows, int pcols, int 
     } else {
         RowArgs ra{};
         ra.src_real = d_psf; ra.src_rows = prows; ra.src_cols = pcols; ra.src_stride = pstride;
-        ra.dst_c = p->filt; ra.M = p->M;
+        ra.dst_c = p->filt; ra.M = p->M; ra.panel_c = p->ppar ? 1 : 0; ra.pstride = p->pstride;
         FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_REAL, ROW_OUT_COMPLEX, false, ra, p->tw_row_f, s));
         ColArgs ca{};
-        ca.data = p->filt; ca.N = p->N;
+        ca.data = p->filt; ca.N = p->N; ca.panel_c = p->ppar ? 1 : 0; ca.pstride = p->pstride;
         FDR_HIP(launch_cols(p->logM, p->mode, COL_FWD, ca, p->tw_col_f, p->tw_col_i, s));
     }
     if (p->mode == FDR_MODE_FAST && !p->panel)  // (the panel path's column pass has written W already)
@@ -590,25 +591,26 @@ int wiener_dev_impl(fdr_plan* p, fdr_plan::Slot& w, const float* d_img, int rows
             ScopedPass t(p, s, kPassRowsFwd);
             RowArgs a{};
             a.src_real = d_img; a.src_rows = rows; a.src_cols = cols; a.src_stride = stride;
-            a.dst_c = w.work; a.M = p->M;
+            a.dst_c = w.work; a.M = p->M; a.panel_c = p->ppar ? 1 : 0; a.pstride = p->pstride;
             FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_REAL, ROW_OUT_COMPLEX, false, a, p->tw_row_f, s));
         }
         {   // B: columns forward + Wiener quotient (:176 second half, :186-224)
             ScopedPass t(p, s, kPassColsWiener);
             ColArgs c{};
-            c.data = w.work; c.filt = p->filt; c.K = p->K; c.N = p->N;
+            c.data = w.work; c.filt = p->filt; c.K = p->K; c.N = p->N; c.panel_c = p->ppar ? 1 : 0; c.pstride = p->pstride;
             FDR_HIP(launch_cols(p->logM, p->mode, COL_FWD_WIENER, c, p->tw_col_f, p->tw_col_i, s));
         }
         {   // C: rows inverse (:229 first half)
             ScopedPass t(p, s, kPassRowsInv);
             RowArgs a{};
-            a.src_c = w.work; a.dst_c = w.work; a.M = p->M;
+            a.src_c = w.work; a.dst_c = w.work; a.M = p->M; a.panel_c = p->ppar ? 1 : 0; a.pstride = p->pstride;
             FDR_HIP(launch_rows(p->logN, p->mode, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, true, a, p->tw_row_i, s));
         }
         {   // D: columns inverse, real plane, min/max (:229 second half, :236-240, minMaxIdx of :246)
             ScopedPass t(p, s, kPassColsInvReal);
             ColArgs c{};
             c.data = w.work; c.dst_real = w.raw; c.mm_part = w.mm_part; c.mm_rows = mm_rows; c.mm_cols = mm_cols; c.N = p->N;
+            c.panel_c = p->ppar ? 1 : 0; c.pstride = p->pstride;
             FDR_HIP(launch_cols(p->logM, p->mode, COL_INV_REAL, c, p->tw_col_f, p->tw_col_i, s));
             n_part = cols_minmax_partials(p->logM, p->N);
         }
@@ -622,11 +624,14 @@ int wiener_dev_impl(fdr_plan* p, fdr_plan::Slot& w, const float* d_img, int rows
     {   // E: normalise to [0,1] and crop (fft/fft_serial.cpp:246, serial.cpp:38)
         ScopedPass t(p, s, kPassNormalize);
         if (n_part <= 0 || n_part > p->mm_part_cap) return fail(FDR_ERR_STATE, "fdr_wiener: min/max partial count out of range");
+        const bool pp = p->ppar && p->mode == FDR_MODE_PARITY && !p->simple;  // the raw plane is panel-major then
         if (n_part <= 4096) {
-            FDR_HIP(launch_normalize(w.raw, p->N, w.mm_part, n_part, nullptr, d_out, rows, cols, out_stride, s));
+            if (pp) FDR_HIP(launch_normalize_panels(w.raw, p->M, p->N, w.mm_part, n_part, nullptr, d_out, rows, cols, out_stride, s));
+            else FDR_HIP(launch_normalize(w.raw, p->N, w.mm_part, n_part, nullptr, d_out, rows, cols, out_stride, s));
         } else {  // many partials (reference-shaped path): fold them once in a separate launch
             FDR_HIP(launch_reduce_minmax(w.mm_part, n_part, w.mm, s));
-            FDR_HIP(launch_normalize(w.raw, p->N, nullptr, 0, w.mm, d_out, rows, cols, out_stride, s));
+            if (pp) FDR_HIP(launch_normalize_panels(w.raw, p->M, p->N, nullptr, 0, w.mm, d_out, rows, cols, out_stride, s));
+            else FDR_HIP(launch_normalize(w.raw, p->N, nullptr, 0, w.mm, d_out, rows, cols, out_stride, s));
         }
     }
     return FDR_OK;
@@ -689,6 +694,17 @@ static int plan_create_impl(fdr_plan* p, int device, int M, int N, int mode, uns
         p->pstride = (size_t)M * 4 + 16;
         p->half = N >= 32 && (flags & FDR_FLAG_FULL_SPECTRUM) == 0;
         p->npanels = p->half ? N / 8 : N / 4;
+        P = (size_t)p->npanels * p->pstride;
+    } else if (mode == FDR_MODE_PARITY && !p->simple) {
+        // the bit-identical mode keeps the reference's pass order and full complex spectrum, but its intermediate is panel-major
+        // too since round 4 (all N/4 panels): the column passes B and D read and write contiguous M x 32-byte tiles instead of
+        // 32 bytes of every row (B 169 -> 88, D 67 -> 55 us per 4096^2 image; A and C pay 9 us each for their 32-byte pieces,
+        // which they reach through an XCD-aware workgroup order, fdr_rows.hip; the raw real plane is panel-major as well and
+        // normalize_panels_kernel turns it back).  381 -> 276 us per 4096^2 image, 1767 -> 1266 at 8192^2.  Same butterflies,
+        // same tables, same bits (every parity test compares with ==).
+        p->ppar = true;
+        p->pstride = (size_t)M * 4 + 16;
+        p->npanels = N / 4;
         P = (size_t)p->npanels * p->pstride;
     }
     std::vector<float2> t;

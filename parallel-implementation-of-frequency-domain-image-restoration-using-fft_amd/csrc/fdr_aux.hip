@@ -335,6 +335,93 @@ hipError_t launch_normalize(const float* raw, int N, const float2* mm_part, int 
     return hipGetLastError();
 }
 
+// ---- the same normalisation from a PANEL-major real plane (parity operator since round 4): a workgroup takes 16 rows x 64
+// columns, reads 16 panels x (16 rows x 16 bytes = 256 contiguous bytes), turns the block through LDS and writes 16 rows x
+// 256 contiguous bytes.  scale / shift and the two roundings exactly as normalize_kernel.
+template <bool VEC4>
+__global__ __launch_bounds__(256) void normalize_panels_kernel(const float* __restrict__ raw, int M, const float2* __restrict__ part, int n_part,
+                                                               const float* __restrict__ mm, float* __restrict__ out, int rows, int cols,
+                                                               int out_stride) {
+    __shared__ float tile[32][132];  // 32 rows x 128 columns (+4: the transposing accesses fall on distinct banks)
+    __shared__ float2 red[4];
+    float mn, mx;
+    if (part != nullptr) {
+        mn = __builtin_inff(); mx = -__builtin_inff();
+        for (int i = threadIdx.x; i < n_part; i += 256) {
+            const float2 p = part[i];
+            mn = fminf(mn, p.x);
+            mx = fmaxf(mx, p.y);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn = fminf(mn, __shfl_xor(mn, off));
+            mx = fmaxf(mx, __shfl_xor(mx, off));
+        }
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = make_float2(mn, mx);
+        __syncthreads();
+        mn = fminf(fminf(red[0].x, red[1].x), fminf(red[2].x, red[3].x));
+        mx = fmaxf(fmaxf(red[0].y, red[1].y), fmaxf(red[2].y, red[3].y));
+    } else {
+        mn = mm[0]; mx = mm[1];
+    }
+    float fscale, fshift;
+    minmax_to_scale_shift(mn, mx, fscale, fshift);
+    typedef float nf4 __attribute__((ext_vector_type(4)));
+    const int cblocks = (cols + 127) / 128, rblocks = (rows + 31) / 32;
+    for (long long bi = blockIdx.x; bi < (long long)cblocks * rblocks; bi += gridDim.x) {
+        const int rb = (int)(bi / cblocks) * 32, cb = (int)(bi % cblocks) * 128;
+        // read: 32 panels x 32 rows of 16 bytes; a wave takes two panels x 32 rows = two runs of 512 contiguous bytes
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = (int)threadIdx.x + 256 * k;  // 0 .. 1023
+            const int pi = e >> 5, ri = e & 31;
+            const int m = rb + ri, c0 = cb + pi * 4;
+            nf4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < rows && c0 < cols) v = __builtin_nontemporal_load(reinterpret_cast<const nf4*>(raw + ((size_t)(c0 >> 2) * (size_t)M + (size_t)m) * 4));  // last use
+            *reinterpret_cast<float4*>(&tile[ri][pi * 4]) = make_float4(v.x, v.y, v.z, v.w);
+        }
+        __syncthreads();
+        // write: a row of the block is 128 columns = 512 contiguous bytes = 32 lanes x 16 bytes
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = (int)threadIdx.x + 256 * k;
+            const int ri = e >> 5, ci = (e & 31) * 4;
+            const int m = rb + ri, c = cb + ci;
+            if (m < rows && c < cols) {
+                const float4 t = *reinterpret_cast<const float4*>(&tile[ri][ci]);
+                float4 o;
+                o.x = t.x * fscale; o.y = t.y * fscale; o.z = t.z * fscale; o.w = t.w * fscale;
+                o.x = o.x + fshift; o.y = o.y + fshift; o.z = o.z + fshift; o.w = o.w + fshift;
+                float* dst = out + (size_t)m * out_stride + c;
+                if (VEC4) {  // cols % 4 == 0, rows of the output 16-byte aligned
+                    nf4 oo; oo.x = o.x; oo.y = o.y; oo.z = o.z; oo.w = o.w;
+                    __builtin_nontemporal_store(oo, reinterpret_cast<nf4*>(dst));  // written once, read by the caller
+                } else {
+                    dst[0] = o.x;
+                    if (c + 1 < cols) dst[1] = o.y;
+                    if (c + 2 < cols) dst[2] = o.z;
+                    if (c + 3 < cols) dst[3] = o.w;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_normalize_panels(const float* raw, int M, int N, const float2* mm_part, int n_part, const float* mm, float* out,
+                                   int rows, int cols, int out_stride, hipStream_t s) {
+    (void)N;
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    const long long nb = (long long)((cols + 127) / 128) * ((rows + 31) / 32);
+    const int grid = nb > 4096 ? 4096 : (int)nb;
+    const bool vec4 = (cols % 4 == 0) && (out_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    if (vec4)
+        hipLaunchKernelGGL(normalize_panels_kernel<true>, dim3(grid), dim3(256), 0, s, raw, M, mm_part, n_part, mm, out, rows, cols, out_stride);
+    else
+        hipLaunchKernelGGL(normalize_panels_kernel<false>, dim3(grid), dim3(256), 0, s, raw, M, mm_part, n_part, mm, out, rows, cols, out_stride);
+    return hipGetLastError();
+}
+
 // ---- utils.hpp:15-24 motionBlurKernel on the device ----
 // The source kernel (row size/2 set to 1/size) is analytic; the inverse affine map is prepared on
 // the host in double exactly as cv::getRotationMatrix2D + cv::warpAffine do, and each destination

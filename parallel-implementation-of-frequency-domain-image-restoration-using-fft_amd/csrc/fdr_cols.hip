@@ -12,6 +12,7 @@
 // column half of fdr_fft2d_c2c in both modes.
 #include "fdr_fft_core.hpp"
 #include "fdr_kernels.hpp"
+#include <type_traits>
 
 namespace fdr {
 
@@ -26,12 +27,6 @@ struct ColGeom {
     // two 512-thread workgroups per CU (4 waves/SIMD) need <= 128 VGPRs; LDS (2 x 74 KB) allows it
     static constexpr int WAVES_PER_SIMD = THREADS >= 512 ? 4 : 1;
 };
-
-__device__ __forceinline__ int col_tile_of_block(int b, int ntiles, int share) {
-    if (share <= 1 || (ntiles % (8 * share)) != 0) return b;
-    const int grp = b / (8 * share), r = b % (8 * share);
-    return grp * 8 * share + (r % 8) * share + (r / 8);
-}
 
 // Addressing discipline for the column tiles: every access is  uniform_base[thread_off]  with a
 // wave-uniform 64-bit base (row block q, kept in SGPRs) and ONE unsigned 32-bit per-thread element
@@ -52,7 +47,9 @@ __device__ __forceinline__ float2 wiener_parity(float2 g, float2 h, float K) {
     o.y = denom != 0.0f ? ni / denom : 0.0f;
     return o;
 }
-template <int LOGM, class Pol, int KIND>
+// PANEL = 1 (parity operator since round 4): the array is panel-major -- a thread group's four columns are ONE contiguous
+// M x 32-byte block, whole 128-byte lines per quad of lanes -- instead of 32 bytes of every row of the row-major array.
+template <int LOGM, class Pol, int KIND, int PANEL>
 __global__ __launch_bounds__(ColGeom<LOGM>::THREADS, ColGeom<LOGM>::WAVES_PER_SIMD) void fft_cols_kernel(const ColArgs a, const float2* __restrict__ tw_fwd,
                                                                           const float2* __restrict__ tw_inv) {
     using St = Steps<LOGM>;
@@ -63,10 +60,15 @@ __global__ __launch_bounds__(ColGeom<LOGM>::THREADS, ColGeom<LOGM>::WAVES_PER_SI
 
     const int N = a.N;
     const int ntiles = (N + Geo::COLS - 1) / Geo::COLS;
-    const int tile = col_tile_of_block(blockIdx.x, ntiles, Geo::SHARE);
+    const int tile = PANEL ? (int)blockIdx.x : col_tile_of_block(blockIdx.x, ntiles, Geo::SHARE);
     const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
     const int col0 = (tile * G + g) * B;
     const bool active = col0 < N;  // N is a multiple of 4 on this path
+    // element offset of (row m, this group's first column): row-major m N + col0; panel-major panel * pstride + 4 m
+    // (one base per thread group + an unsigned 32-bit element offset per row: M N < 2^32 elements)
+    const size_t pbase = PANEL ? (size_t)(col0 >> 2) * a.pstride : (size_t)col0;
+    const unsigned rstep = PANEL ? 4u : (unsigned)N;
+    float2* __restrict__ gdata = a.data + pbase;
     float2* grp_lds = lds + g * 2 * St::BUF;
 
     constexpr bool kInverseOnly = (KIND == COL_INV || KIND == COL_INV_REAL);
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(ColGeom<LOGM>::THREADS, ColGeom<LOGM>::WAVES_PER_SI
         for (int q = 0; q < Core::RHO0; ++q) {
             const int m = Core::in_index(tid, u, q);
             const int s = u * Core::RHO0 + q;
-            if (active) load4(a.data + (size_t)m * N + col0, v[0][s], v[1][s], v[2][s], v[3][s]);
+            if (active) load4(gdata + (unsigned)m * rstep, v[0][s], v[1][s], v[2][s], v[3][s]);
             else v[0][s] = v[1][s] = v[2][s] = v[3][s] = make_float2(0.f, 0.f);
         }
 
@@ -95,23 +97,41 @@ __global__ __launch_bounds__(ColGeom<LOGM>::THREADS, ColGeom<LOGM>::WAVES_PER_SI
 #pragma unroll
                 for (int q = 0; q < Core::RHOL; ++q) {
                     const int s = u * Core::RHOL + q;
-                    store4(a.data + (size_t)Core::out_index(tid, u, q) * N + col0, v[0][s], v[1][s], v[2][s], v[3][s]);
+                    store4(gdata + (unsigned)Core::out_index(tid, u, q) * rstep, v[0][s], v[1][s], v[2][s], v[3][s]);
                 }
         }
     } else if (KIND == COL_FWD_WIENER) {
-        if (active) {
+        // The quotient needs IEEE square roots and divisions -- a dozen temporaries each -- beside the 64 registers of the tile,
+        // and at 128 registers per lane hipcc spilled 15-39 of them (PMC: +23 % HBM writes, +12 % reads in this pass).  The
+        // exchange buffers are idle by now: the second half of the tile (slots 4..7) waits THERE while the first half is
+        // divided, 64 KB of LDS traffic per tile instead of scratch memory.  Each thread reads back only what it wrote.
+        constexpr int HALF = 4;
+        static_assert(2 * St::BUF >= 4 * HALF * T, "the parked half tile fits the group's exchange buffers");
+        __syncthreads();  // every wave has read its last exchange values
 #pragma unroll
-            for (int u = 0; u < Core::NUL; ++u)
+        for (int s = HALF; s < 8; ++s)
 #pragma unroll
-                for (int q = 0; q < Core::RHOL; ++q) {
-                    const int s = u * Core::RHOL + q;
-                    const size_t off = (size_t)Core::out_index(tid, u, q) * N + col0;
-                    float2 h0, h1, h2, h3;
-                    load4(a.filt + off, h0, h1, h2, h3);
-                    store4(a.data + off, wiener_parity(v[0][s], h0, a.K), wiener_parity(v[1][s], h1, a.K),
+            for (int b = 0; b < B; ++b) grp_lds[((s - HALF) * B + b) * T + tid] = v[b][s];
+        auto quotient_rows = [&](int s0) {
+#pragma unroll
+            for (int s = s0; s < s0 + HALF; ++s) {
+                const int u = s / Core::RHOL, q = s % Core::RHOL;
+                const unsigned off = (unsigned)Core::out_index(tid, u, q) * rstep;
+                float2 h0, h1, h2, h3;
+                if (active) {
+                    load4(a.filt + pbase + off, h0, h1, h2, h3);
+                    store4(gdata + off, wiener_parity(v[0][s], h0, a.K), wiener_parity(v[1][s], h1, a.K),
                            wiener_parity(v[2][s], h2, a.K), wiener_parity(v[3][s], h3, a.K));
                 }
-        }
+                asm volatile("" ::: "memory");  // (one row of quotients at a time)
+            }
+        };
+        quotient_rows(0);
+#pragma unroll
+        for (int s = HALF; s < 8; ++s)
+#pragma unroll
+            for (int b = 0; b < B; ++b) v[b][s] = grp_lds[((s - HALF) * B + b) * T + tid];
+        quotient_rows(HALF);
     } else if (KIND == COL_INV_REAL) {
         float mn = __builtin_inff(), mx = -__builtin_inff();
         if (active) {
@@ -122,7 +142,9 @@ __global__ __launch_bounds__(ColGeom<LOGM>::THREADS, ColGeom<LOGM>::WAVES_PER_SI
                     const int s = u * Core::RHOL + q;
                     const int m = Core::out_index(tid, u, q);
                     const float4 r = make_float4(v[0][s].x, v[1][s].x, v[2][s].x, v[3][s].x);
-                    *reinterpret_cast<float4*>(a.dst_real + (size_t)m * N + col0) = r;
+                    // (real plane: row-major, or panel-major with panels exactly 4 M floats apart -- it fits the M x N plane)
+                    if (PANEL) *reinterpret_cast<float4*>(a.dst_real + ((size_t)(col0 >> 2) * (size_t)St::L + (size_t)m) * 4) = r;
+                    else *reinterpret_cast<float4*>(a.dst_real + (size_t)m * N + col0) = r;
                     if (m < a.mm_rows) {
                         if (col0 + 0 < a.mm_cols) { mn = fminf(mn, r.x); mx = fmaxf(mx, r.x); }
                         if (col0 + 1 < a.mm_cols) { mn = fminf(mn, r.y); mx = fmaxf(mx, r.y); }
@@ -139,7 +161,14 @@ template <int LOGM, class Pol, int KIND>
 static hipError_t launch_cols_one(const ColArgs& a, const float2* twf, const float2* twi, hipStream_t s) {
     using Geo = ColGeom<LOGM>;
     const int ntiles = (a.N + Geo::COLS - 1) / Geo::COLS;
-    hipLaunchKernelGGL((fft_cols_kernel<LOGM, Pol, KIND>), dim3(ntiles), dim3(Geo::THREADS), 0, s, a, twf, twi);
+    if constexpr (std::is_same<Pol, PolicyParity>::value && (KIND == COL_FWD || KIND == COL_FWD_WIENER || KIND == COL_INV_REAL)) {
+        if (a.panel_c) {
+            hipLaunchKernelGGL((fft_cols_kernel<LOGM, Pol, KIND, 1>), dim3(ntiles), dim3(Geo::THREADS), 0, s, a, twf, twi);
+            return hipGetLastError();
+        }
+    }
+    if (a.panel_c) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((fft_cols_kernel<LOGM, Pol, KIND, 0>), dim3(ntiles), dim3(Geo::THREADS), 0, s, a, twf, twi);
     return hipGetLastError();
 }
 

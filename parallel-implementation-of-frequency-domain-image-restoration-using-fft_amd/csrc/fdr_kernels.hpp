@@ -50,6 +50,14 @@ struct NormBatch {
     int nimg;
 };
 
+// Workgroups that touch the same 128-byte lines -- `share` consecutive tiles -- are placed on ONE XCD (workgroup b lands
+// on XCD b % 8) and dispatched back to back, so that their partial lines meet in that XCD's L2: tile of workgroup b.
+__host__ __device__ __forceinline__ int col_tile_of_block(int b, int ntiles, int share) {
+    if (share <= 1 || (ntiles % (8 * share)) != 0) return b;
+    const int grp = b / (8 * share), r = b % (8 * share);
+    return grp * 8 * share + (r % 8) * share + (r / 8);
+}
+
 struct RowArgs {
     // input
     const float* src_real;  // ROW_IN_REAL: rows x cols image, zero-padded on the fly to M x L
@@ -67,6 +75,8 @@ struct RowArgs {
     int half;           // rows4 packed kernels: half (Hermitian) spectrum, N/8 panels
     int num_cu;         // rows4 persistent kernels: CUs of the device
     RowBatch batch;     // rows4 packed kernels: several images per launch
+    int panel_c;        // launch_rows (parity operator): the complex side(s) are PANEL-major, full spectrum: element (m, n) at
+                        // (n >> 2) * pstride + m * 4 + (n & 3) -- the column passes then work on contiguous tiles
 };
 
 // up to kMaxGroup images' spectra handled by ONE pass-B' launch (their panels form one tile sequence)
@@ -89,6 +99,7 @@ struct ColArgs {
     int nvalid;       // COL_FWD_FILTER: rows of the panels that hold data (a multiple of 4); the others are read as zero
     size_t pstride;   // panel kernels: panel stride in float2 elements
     int num_cu;       // CUs of the device (persistent pass B' launches one workgroup per CU)
+    int panel_c;      // launch_cols (parity operator): data / filt panel-major (pstride), dst_real panel-major with stride 4 M floats
 };
 
 // launchers (fdr_rows.hip / fdr_cols.hip); logl = log2 of the transform length, 3..13
@@ -128,6 +139,9 @@ int cols_minmax_partials(int logm, int N);
 // mm_part != nullptr: every workgroup folds the n_part partials itself; else mm = {min, max} from launch_reduce_minmax
 hipError_t launch_normalize(const float* raw, int N, const float2* mm_part, int n_part, const float* mm, float* out,
                             int rows, int cols, int out_stride, hipStream_t s, const NormBatch* batch = nullptr);
+// the same from a PANEL-major real plane (panel p = columns 4 p .. 4 p + 3, M rows of 4 floats, panels 4 M floats apart)
+hipError_t launch_normalize_panels(const float* raw, int M, int N, const float2* mm_part, int n_part, const float* mm, float* out,
+                                   int rows, int cols, int out_stride, hipStream_t s);
 hipError_t launch_psf_motion(int size, double angle_deg, float* d_out, hipStream_t s);
 // cv::warpAffine defaults (bilinear, constant 0 border) on a single-channel float image; fwd = the 2 x 3 matrix as cv::warpAffine takes it
 hipError_t launch_warp_affine(const float* src, int srows, int scols, int sstride, const double fwd[6], float* dst, int drows, int dcols,

@@ -8,6 +8,7 @@
 // t + (L/rho) q, so each of the rho wave-level accesses is one contiguous sweep of the row.
 #include "fdr_fft_core.hpp"
 #include "fdr_kernels.hpp"
+#include <type_traits>
 
 namespace fdr {
 
@@ -20,7 +21,14 @@ struct RowGeom {
 
 // INV matters only to the fast policy (it conjugates the hoisted forward twiddles); the parity
 // policy receives a direction-specific table and is instantiated with INV = false only.
-template <int LOGL, class Pol, int IN, int OUT, bool INV>
+// PANEL = 1 (parity operator since round 4): the complex side(s) are panel-major, so that the column passes work on
+// contiguous tiles.  A row then touches 32 bytes (its four columns) of a 128-byte line that it shares with three neighbouring
+// rows; the workgroups of such a 4-row group are placed on one XCD back to back (col_tile_of_block) so that the four
+// partial lines meet in that XCD's L2 and HBM sees whole lines.  (A kernel that gives a thread group FOUR rows -- whole lines,
+// one 32-byte row of a panel per lane and a 4 x 4 transpose inside the quad of lanes, as the fast mode's inverse row passes
+// do -- was built, passed the tests and measured SLOWER at every size: A 61 -> 84, C 63 -> 76 us per 4096^2 image; four
+// parity transforms per thread do not fit 128 registers without spills at 4096 points and more.)
+template <int LOGL, class Pol, int IN, int OUT, bool INV, int PANEL>
 __global__ __launch_bounds__(RowGeom<LOGL>::THREADS) void fft_rows_kernel(const RowArgs a, const float2* __restrict__ tw) {
     using St = Steps<LOGL>;
     using Core = FftCore<LOGL, 1, 1, Pol>;
@@ -28,7 +36,9 @@ __global__ __launch_bounds__(RowGeom<LOGL>::THREADS) void fft_rows_kernel(const 
     __shared__ float2 lds[G * St::BUF];
 
     const int g = threadIdx.x >> St::LOGT, tid = threadIdx.x & (T - 1);
-    const int row = blockIdx.x * G + g;
+    constexpr int kShare = G >= 4 ? 1 : 4 / G;  // workgroups per 4-row group
+    const int blk = PANEL ? col_tile_of_block((int)blockIdx.x, (int)gridDim.x, kShare) : (int)blockIdx.x;
+    const int row = blk * G + g;
     const bool active = row < a.M;
 
     typename Core::Bases bases;
@@ -44,7 +54,7 @@ __global__ __launch_bounds__(RowGeom<LOGL>::THREADS) void fft_rows_kernel(const 
             if (IN == ROW_IN_REAL) {
                 if (active && row < a.src_rows && n < a.src_cols) x.x = a.src_real[(size_t)row * a.src_stride + n];
             } else {
-                if (active) x = a.src_c[(size_t)row * L + n];
+                if (active) x = PANEL ? a.src_c[(size_t)(n >> 2) * a.pstride + (size_t)row * 4 + (n & 3)] : a.src_c[(size_t)row * L + n];
             }
             v[0][u * Core::RHO0 + q] = x;
         }
@@ -56,8 +66,11 @@ __global__ __launch_bounds__(RowGeom<LOGL>::THREADS) void fft_rows_kernel(const 
 #pragma unroll
             for (int u = 0; u < Core::NUL; ++u)
 #pragma unroll
-                for (int q = 0; q < Core::RHOL; ++q)
-                    a.dst_c[(size_t)row * L + Core::out_index(tid, u, q)] = v[0][u * Core::RHOL + q];
+                for (int q = 0; q < Core::RHOL; ++q) {
+                    const int n = Core::out_index(tid, u, q);
+                    if (PANEL) a.dst_c[(size_t)(n >> 2) * a.pstride + (size_t)row * 4 + (n & 3)] = v[0][u * Core::RHOL + q];
+                    else a.dst_c[(size_t)row * L + n] = v[0][u * Core::RHOL + q];
+                }
         }
     } else {
         float mn = __builtin_inff(), mx = -__builtin_inff();
@@ -83,12 +96,24 @@ template <int LOGL, class Pol, bool INV>
 static hipError_t launch_rows_io(RowIn in, RowOut out, const RowArgs& a, const float2* tw, hipStream_t s) {
     constexpr int G = RowGeom<LOGL>::G, THREADS = RowGeom<LOGL>::THREADS;
     const dim3 grid((a.M + G - 1) / G), block(THREADS);
+    if constexpr (std::is_same<Pol, PolicyParity>::value && LOGL >= 2) {  // (panel-major: the parity operator only; rows of >= 4 columns)
+        if (a.panel_c) {
+            if (in == ROW_IN_REAL && out == ROW_OUT_COMPLEX)
+                hipLaunchKernelGGL((fft_rows_kernel<LOGL, Pol, ROW_IN_REAL, ROW_OUT_COMPLEX, INV, 1>), grid, block, 0, s, a, tw);
+            else if (in == ROW_IN_COMPLEX && out == ROW_OUT_COMPLEX)
+                hipLaunchKernelGGL((fft_rows_kernel<LOGL, Pol, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, INV, 1>), grid, block, 0, s, a, tw);
+            else
+                return hipErrorInvalidValue;
+            return hipGetLastError();
+        }
+    }
+    if (a.panel_c) return hipErrorInvalidValue;
     if (in == ROW_IN_REAL && out == ROW_OUT_COMPLEX)
-        hipLaunchKernelGGL((fft_rows_kernel<LOGL, Pol, ROW_IN_REAL, ROW_OUT_COMPLEX, INV>), grid, block, 0, s, a, tw);
+        hipLaunchKernelGGL((fft_rows_kernel<LOGL, Pol, ROW_IN_REAL, ROW_OUT_COMPLEX, INV, 0>), grid, block, 0, s, a, tw);
     else if (in == ROW_IN_COMPLEX && out == ROW_OUT_COMPLEX)
-        hipLaunchKernelGGL((fft_rows_kernel<LOGL, Pol, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, INV>), grid, block, 0, s, a, tw);
+        hipLaunchKernelGGL((fft_rows_kernel<LOGL, Pol, ROW_IN_COMPLEX, ROW_OUT_COMPLEX, INV, 0>), grid, block, 0, s, a, tw);
     else if (in == ROW_IN_COMPLEX && out == ROW_OUT_REAL_MINMAX)
-        hipLaunchKernelGGL((fft_rows_kernel<LOGL, Pol, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, INV>), grid, block, 0, s, a, tw);
+        hipLaunchKernelGGL((fft_rows_kernel<LOGL, Pol, ROW_IN_COMPLEX, ROW_OUT_REAL_MINMAX, INV, 0>), grid, block, 0, s, a, tw);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
