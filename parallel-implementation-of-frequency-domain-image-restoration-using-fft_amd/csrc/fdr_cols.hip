@@ -161,7 +161,11 @@ template <int LOGM, class Pol, int KIND>
 static hipError_t launch_cols_one(const ColArgs& a, const float2* twf, const float2* twi, hipStream_t s) {
     using Geo = ColGeom<LOGM>;
     const int ntiles = (a.N + Geo::COLS - 1) / Geo::COLS;
-    if constexpr (std::is_same<Pol, PolicyParity>::value && (KIND == COL_FWD || KIND == COL_FWD_WIENER || KIND == COL_INV_REAL)) {
+    if constexpr (KIND == COL_FWD_WIENER || KIND == COL_INV_REAL) {  // the operator's own passes: panel-major only since round 4
+        if (!a.panel_c) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((fft_cols_kernel<LOGM, Pol, KIND, 1>), dim3(ntiles), dim3(Geo::THREADS), 0, s, a, twf, twi);
+        return hipGetLastError();
+    } else if constexpr (std::is_same<Pol, PolicyParity>::value && KIND == COL_FWD) {  // (the PSF spectrum of the parity operator)
         if (a.panel_c) {
             hipLaunchKernelGGL((fft_cols_kernel<LOGM, Pol, KIND, 1>), dim3(ntiles), dim3(Geo::THREADS), 0, s, a, twf, twi);
             return hipGetLastError();
