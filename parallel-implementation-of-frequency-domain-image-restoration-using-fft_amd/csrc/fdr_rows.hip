@@ -27,7 +27,11 @@ struct RowGeom {
 // partial lines meet in that XCD's L2 and HBM sees whole lines.  (A kernel that gives a thread group FOUR rows -- whole lines,
 // one 32-byte row of a panel per lane and a 4 x 4 transpose inside the quad of lanes, as the fast mode's inverse row passes
 // do -- was built, passed the tests and measured SLOWER at every size: A 61 -> 84, C 63 -> 76 us per 4096^2 image; four
-// parity transforms per thread do not fit 128 registers without spills at 4096 points and more.)
+// parity transforms per thread do not fit 128 registers without spills at 4096 points and more.  The same with 16 values per
+// thread and a radix-16 step of the recurrence tables -- 256 threads per 4-row group at 4096 points, no spills once the rows
+// of a stage are pinned one after the other -- passed every test too and was no better: A 66 -> 67, C 66 -> 83 us at 4096^2,
+// 20 -> 25 / 21 -> 29 us at 2048^2, 235 -> 290 / 381 -> 386 us at 8192^2.  The row passes are not bound by the size of their
+// pieces; the one-row kernels stay.)
 template <int LOGL, class Pol, int IN, int OUT, bool INV, int PANEL>
 __global__ __launch_bounds__(RowGeom<LOGL>::THREADS) void fft_rows_kernel(const RowArgs a, const float2* __restrict__ tw) {
     using St = Steps<LOGL>;
