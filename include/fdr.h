@@ -82,7 +82,11 @@ int fdr_optimal_dft_size(int n);
  *    min/max scratch for one device.  Replaces the per-call cudaMalloc/cudaFree block of
  *    fft/fft_gpu.cu:304-322,389-393.  One host thread at a time per plan.  fdr_plan_destroy
  *    called while the process is already running its exit handlers (static destructors of a
- *    caller) frees the host side only: the HIP runtime may be gone by then.              */
+ *    caller) frees the host side only: the HIP runtime may be gone by then.
+ *    Dimensions: powers of two up to 32768 (a dimension above 8192 is transformed in 8192-point
+ *    blocks plus radix-2 stages in global memory: the reference's serial path takes any power
+ *    of two, fft/fft_serial.cpp:90-108); with FDR_FLAG_ANY_SIZE also non-powers of two up to
+ *    4096 (naive DFT).                                                                    */
 int fdr_plan_create(int device, int M, int N, int mode, unsigned flags, fdr_plan** out);
 int fdr_plan_destroy(fdr_plan* plan);
 int fdr_plan_dims(const fdr_plan* plan, int* M, int* N, int* mode);
@@ -185,8 +189,9 @@ int fdr_fft2d_c2c_dev(fdr_plan* plan, float* d_data, int inverse, void* stream);
 
 /* -- fft_gpu::fft_radix2_kernel / transform_row_kernel / dft_naive_kernel (fft/fft.hpp:35-39;
  *    declared, never defined in the reference): 1-D unscaled transform of n interleaved
- *    complex values given by host pointer.  fft1d: power-of-two n (radix-2) else naive DFT,
- *    as fft_serial::transform_row_inplace dispatches (fft/fft_serial.cpp:100-101).        */
+ *    complex values given by host pointer.  fft1d: power-of-two n up to 32768 (radix-2) else
+ *    naive DFT (n <= 4096), as fft_serial::transform_row_inplace dispatches
+ *    (fft/fft_serial.cpp:100-101).                                                        */
 int fdr_fft1d_c2c(float* data_host, int n, int inverse, int mode);
 int fdr_dft_naive_c2c(float* data_host, int n, int inverse);
 

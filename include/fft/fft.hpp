@@ -198,7 +198,8 @@ inline void dft_naive_kernel(float* data, int n, bool inverse) { FDR_CHECK(fdr_d
 inline void transform_row_kernel(float* rowPtr, int N, bool inverse) { FDR_CHECK(fdr_fft1d_c2c(rowPtr, N, inverse ? 1 : 0, FDR_MODE_PARITY)); }
 
 // fft/fft.hpp:40-42: in-place unscaled 2-D transform of a CV_32FC2 Mat (rows, transpose, rows, transpose); any size
-// up to 8192 (non-powers of two up to 4096: naive DFT along that dimension, as fft_serial.cpp:100-101)
+// up to 32768 for powers of two (above 8192: 8192-point blocks + radix-2 stages in global memory), non-powers of two up to
+// 4096 (naive DFT along that dimension, as fft_serial.cpp:100-101)
 inline void my_dft2D(Mat& complexMat, bool inverse) {
     if (complexMat.type() != CV_32FC2) { std::fprintf(stderr, "Error: %s:%d, my_dft2D needs CV_32FC2\n", __FILE__, __LINE__); std::exit(1); }
     const int M = complexMat.rows, N = complexMat.cols;
