@@ -63,5 +63,10 @@ make -s -C tools/microbench rmw_bench
 python3 bench.py --size 2048 --total-batch 512 --steps 10 --warmup 2 --repeats 3 > $OUT/config5_one_gpu.log 2>&1; echo "config5_one_gpu rc=$?" >> $OUT/status.txt
 python3 bench.py --size 1024 --batch 256 --steps 10 --warmup 2 --repeats 3 > $OUT/config2_size.log 2>&1; echo "config2_size rc=$?" >> $OUT/status.txt
 python3 bench.py --size 8192 --batch 24 --steps 6 --warmup 2 --repeats 3 --cpu-size 8192 > $OUT/config4_size.log 2>&1; echo "config4_size rc=$?" >> $OUT/status.txt
+# the bench line once more, now WITH the PMC bytes of this very collection: summarize_profiles.py writes profiles/traffic.json (entries carry the
+# fingerprint of csrc/ recorded above) into this copy of the tree, and bench.py reports roofline.traffic / frac_by_counters only for a matching tree
+python3 tools/summarize_profiles.py $TAG > $OUT/summarize_on_box.log 2>&1; echo "summarize_on_box rc=$?" >> $OUT/status.txt
+python3 bench.py > $OUT/bench_with_traffic.log 2>&1; echo "bench_with_traffic rc=$?" >> $OUT/status.txt
+grep '^{' $OUT/bench_with_traffic.log | tail -n 1 > $OUT/bench_line.json
 cat $OUT/status.txt
 cut -c1-400 $OUT/bench_line.json
