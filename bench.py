@@ -145,6 +145,9 @@ def _cpu_baseline_pinned(o, size, core):
 
 def main():
     args = parse()
+    # multi-process GPU work on this pool needs dmabuf IPC (RCCL / hipIpc fail with the legacy mode): keep the setting in
+    # whatever environment this process and the ranks it may launch run in
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
         # convenience: re-launch under torch.distributed.run as a child (nothing has touched the GPU yet)

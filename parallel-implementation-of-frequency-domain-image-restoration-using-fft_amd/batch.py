@@ -44,6 +44,7 @@ class Comm:
             import datetime
             import torch.distributed as dist
             if not dist.is_initialized():
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL on this pool: dmabuf IPC only
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", "29511")
                 if timeout_s is None:
