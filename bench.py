@@ -402,6 +402,7 @@ def main():
                   "total_batch": args.total_batch or None,
                   "mode": args.mode, "spectrum": spectrum, "streams": args.streams, "images_per_launch": args.group,
                   "parallelism": "images sharded over %d rank(s), no data-path collective" % world,
+                  "collectives": comm.collectives(),  # "rccl", or "gloo (...)" when asked for or when the RCCL group could not be built
                   "normalize_area": "padded (serial semantics)",
                   "repeats": len(reps), "value_min": round(vals[0], 1), "value_max": round(vals[-1], 1),
                   "value_with_psf_recompute": round(psf_images * P / 1e6 / psf_elapsed, 1) if (psf_elapsed and psf_images) else None,

@@ -35,15 +35,15 @@ def alltoall_blocks(comm, send, send_counts, recv_counts):
     import torch
     if comm.dist is None:
         return send.clone()
-    if comm.dist.get_backend() == "nccl":
+    if comm.backend == "nccl":  # (Comm: the proven RCCL group; else its gloo group, staged through the host)
         recv = torch.empty(int(sum(recv_counts)), dtype=send.dtype, device=send.device)
         comm._guard("all_to_all_single", lambda: comm.dist.all_to_all_single(
-            recv, send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts)))
+            recv, send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=comm.group))
         return recv
     h_send = send.detach().cpu().contiguous()
     h_recv = torch.empty(int(sum(recv_counts)), dtype=send.dtype)
     comm._guard("all_to_all_single", lambda: comm.dist.all_to_all_single(
-        h_recv, h_send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts)))
+        h_recv, h_send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=comm.group))
     return h_recv.to(send.device)
 
 

@@ -21,10 +21,12 @@ def main():
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     batch = importlib.import_module(PKG + ".batch")
-    # Comm's OWN set-up, as bench.py --gpus N runs it on every rank: init_process_group(backend="nccl", device_id=cuda:0,
-    # timeout=...), collectives through the guard that turns a failure into a message and a non-zero exit
+    # Comm's OWN set-up, as bench.py --gpus N runs it on every rank: a gloo default group, an RCCL group beside it proven
+    # with one all-reduce on the device, the gloo consensus, then every collective of the run on the RCCL group -- through
+    # the guard that turns a failure into a message and a non-zero exit
     comm = batch.Comm(backend="nccl", device=dev)
-    assert comm.dist is not None and dist.is_initialized() and dist.get_backend() == "nccl"
+    assert comm.dist is not None and dist.is_initialized() and dist.get_backend() == "gloo"
+    assert comm.backend == "nccl" and comm.group is not None and comm.collectives() == "rccl", (comm.backend, comm.fallback_reason)
     comm.barrier()
     mx, mn = comm.allreduce_max(1.25), comm.allreduce_min(-3.5)
     sm = comm.allreduce_sum([1, 2.5, 4])
@@ -35,7 +37,7 @@ def main():
     dt = batch.timed_steps(comm, lambda: calls.append(1), torch.cuda.synchronize, steps=3, warmup=1)
     ok = (mx == 1.25 and mn == -3.5 and sm == [1.0, 2.5, 4.0] and int(blk.to(torch.int64).sum().item()) == (1 << 16) * ((1 << 16) - 1) // 2
           and len(calls) == 4 and dt >= 0.0)
-    print(json.dumps({"ok": bool(ok), "backend": dist.get_backend()}))
+    print(json.dumps({"ok": bool(ok), "backend": comm.backend, "collectives": comm.collectives()}))
     comm.close()
 
 

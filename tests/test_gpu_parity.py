@@ -811,6 +811,26 @@ def test_rccl_single_rank_smoke():
     assert out["ok"] is True and out["backend"] == "nccl", out
 
 
+def test_rccl_refusal_falls_back_to_gloo_by_consensus():
+    """The batched mode has no data-path collective, so a rendezvous problem must not cost a multi-GPU run: bench.py asked for
+    "nccl" with TWO ranks on the ONE GPU of the test box -- which RCCL refuses ("invalid usage") -- must notice it on every
+    rank (proof all-reduce on the RCCL group), agree over the gloo group, and finish with a valid line that says so."""
+    import json
+    import subprocess
+    import sys
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    env = dict(_os.environ, MASTER_PORT="29577", FDR_RCCL_PROBE_TIMEOUT_S="60")
+    r = subprocess.run([sys.executable, _os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "nccl", "--one-device", "--size", "512",
+                        "--batch", "4", "--steps", "2", "--warmup", "1", "--repeats", "1", "--no-psf-recompute", "--no-parity-leg",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["check"]["ranks_ok"] == 2 and d["check"]["images_done"] == d["check"]["images_expected"]
+    assert d["config"]["collectives"].startswith("gloo (rccl unavailable"), d["config"]["collectives"]
+    assert "RCCL group unavailable" in r.stderr
+
+
 def test_cat_picture_through_both_clis(fdr, oracle, tmp_path):
     """BASELINE config 1's named input: `./serial input/cat_blurred.png 50 30` (782 x 1920 -> 1024 x 2048).  This is the
     picture whose minimum lies in the PADDING (normalising over the cropped area instead would move the
