@@ -61,11 +61,29 @@ class Comm:
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", "29511")
                 os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
+                if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+                    # one node: gloo on the loopback interface -- its default is to resolve the HOST NAME, which containers
+                    # do not always do
+                    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
                 self.backend = "gloo"
-                self._guard("init_process_group", lambda: dist.init_process_group(
-                    backend="gloo", rank=self.rank, world_size=self.world, timeout=datetime.timedelta(seconds=timeout_s)))
+                td = datetime.timedelta(seconds=timeout_s)
                 if want == "nccl":
+                    try:
+                        dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world, timeout=td)
+                    except BaseException as e:  # noqa: BLE001 -- no gloo here: RCCL alone, as before round 4
+                        if isinstance(e, (KeyboardInterrupt, SystemExit)):
+                            raise
+                        sys.stderr.write("fdr.batch: rank %d/%d: gloo group unavailable (%s: %s); RCCL alone\n"
+                                         % (self.rank, self.world, type(e).__name__, str(e).splitlines()[0] if str(e) else ""))
+                        self.backend = "nccl"
+                        kw = {"device_id": device} if device is not None else {}
+                        self._guard("init_process_group", lambda: dist.init_process_group(
+                            backend="nccl", rank=self.rank, world_size=self.world, timeout=td, **kw))
+                        return
                     self._try_rccl(datetime.timedelta(seconds=float(os.environ.get("FDR_RCCL_PROBE_TIMEOUT_S", "120"))))
+                else:
+                    self._guard("init_process_group", lambda: dist.init_process_group(
+                        backend="gloo", rank=self.rank, world_size=self.world, timeout=td))
             else:  # a group the caller made: use it as it is
                 self.backend = dist.get_backend()
 
