@@ -1432,6 +1432,14 @@ int fdr_slab_rows_fft_dev(fdr_plan* p, float* d_complex, int rows, int dim, int 
     hipStream_t s = (hipStream_t)stream;
     if (naive) return fail(FDR_ERR_ARG, "fdr_slab_rows_fft_dev: power-of-two dimensions only");
     float2* d = reinterpret_cast<float2*>(d_complex);
+    if (logl > kMaxLdsLog) {  // more than 8192 points: 8192-point blocks + global radix-2 stages (fdr_aux.hip); stream-ordered scratch
+        float2* tmp = nullptr;
+        FDR_HIP(hipMallocAsync((void**)&tmp, (size_t)rows * L * sizeof(float2), s));
+        const hipError_t e = long_rows_dev(d, tmp, (size_t)rows, L, logl, p->mode, inverse != 0, twf, twi, s);
+        (void)hipFreeAsync(tmp, s);
+        FDR_HIP(e);
+        return FDR_OK;
+    }
     if (L >= 8) {
         RowArgs ra{};
         ra.src_c = d; ra.dst_c = d; ra.M = rows;

@@ -1081,7 +1081,8 @@ def test_constant_image_normalises_to_zero(fdr, oracle):
         assert np.all(got == 0.0)
 
 
-@pytest.mark.parametrize("rows,cols,world,extra", [(1024, 2048, 2, []), (782, 1920, 2, []), (100, 200, 3, ["--cropped"]), (64, 64, 1, [])])
+@pytest.mark.parametrize("rows,cols,world,extra", [(1024, 2048, 2, []), (782, 1920, 2, []), (100, 200, 3, ["--cropped"]), (64, 64, 1, []),
+                                                   (60, 9000, 2, []), (9000, 60, 2, [])])  # (the last two: 16384-point rows / columns, round 4)
 def test_single_image_slab_mode_equals_single_gpu(rows, cols, world, extra):
     """SURVEY 8f-3 / fft/fft_mpi.cpp:170-307: ONE image as row slabs over `world` ranks, the 2-D transform as local row
     passes + all-to-all transposes (..._amd/slab.py over the fdr_slab_* kernels).  Rehearsal on one GPU (every rank on
